@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- GloVe pair-updates/sec at dim=200 on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (ge_glove_epoch: the AdaGrad pair-update kernel over every
+nonzero this rank owns) over the synthetic co-occurrence matrix; inputs are resident in HBM before
+the timed region.  Weak scaling: every GPU owns ROWS_PER_GPU focus rows and ~NNZ_PER_GPU nonzeros,
+the context factors are replicated and reconciled by a sum-of-deltas all-reduce (RCCL) per step,
+so at 8 GPUs the job is BASELINE config C4 (5 M vertices / 1 B nonzeros / dim 200).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (HIP-event
+kernel time, algorithmic bytes 16*D+28 read + 16*D+16 written per update) and, at N=1,
+`cpu_baseline` (the oracle's Hogwild restatement of Adagrad.createJob on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "graph-embeddings_amd"))
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dim", type=int, default=200)
+    ap.add_argument("--rows-per-gpu", type=int, default=625_000)
+    ap.add_argument("--nnz-per-gpu", type=int, default=125_000_000)
+    ap.add_argument("--method", default="glove", choices=["glove", "pglove"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--sync-every", type=int, default=1, help="steps between context all-reduces (N>1)")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, V, D, I, J, X, xmax):
+    """Oracle (CPU restatement, kind 'port') timed on a bounded sample of the same workload.
+    Only this leg of bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle as O
+    O.build()
+    cores = max((os.cpu_count() or 2) - 1, 1)          # Configuration.getThreads() default: cores - 1
+    kind = O.COST_GLOVE if args.method == "glove" else O.COST_PGLOVE
+    n = len(I)
+    pick = np.argsort(np.random.default_rng(1).integers(0, 1 << 62, size=min(n, 4_000_000)), kind="stable")
+
+    def run(m):
+        sel = (pick[:m].astype(np.int64) * max(n // len(pick), 1)) % n
+        g = O.Glove(V, D, I[sel], J[sel], X[sel], xmax, kind, seed=42, threads=cores)
+        t0 = time.perf_counter()
+        g.epoch(race=True, shuffle=False)
+        dt = time.perf_counter() - t0
+        g.close()
+        return m / dt, dt
+
+    probe = min(200_000, len(pick))
+    rate, _ = run(probe)
+    m = int(min(len(pick), max(probe, rate * args.cpu_seconds)))
+    rate, dt = run(m)
+    return {"value": rate, "unit": "pair-updates/s", "cores": cores, "kind": "port",
+            "sample": "%d nonzeros drawn at a fixed stride from the same matrix, 1 Hogwild pass, %.1f s; "
+                      "C restatement of Adagrad.createJob (flat arrays: faster than the Java loop, baseline only)"
+                      % (m, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import geglove
+    from geglove import capi, synth, parallel
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if capi.lib().ge_device_count() <= 0:
+        raise SystemExit("bench.py needs a gfx950 GPU: " + capi.lib().ge_last_error().decode())
+
+    D = args.dim
+    V = args.rows_per_gpu * world
+    rows = parallel.shard_rows(V, world, rank)
+    t_gen = time.perf_counter()
+    I, J, X, xmax = synth.synthetic_coo_shard(V, rows, args.nnz_per_gpu, seed=0xC0FFEE)
+    t_gen = time.perf_counter() - t_gen
+    n_local = int(I.shape[0])
+
+    cfg = geglove.Configuration({
+        "graph": "synthetic", "method": args.method, "dim": D, "threads": 1,
+        "bca": {"alpha": 0.1, "epsilon": 1e-3, "directed": True},
+        "opt": {"method": "adagrad", "tolerance": 0, "maxiter": args.steps},
+        "output": {"uri": []},
+        "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank,
+                   "row_range": rows if world > 1 else (0, 0)}})
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+
+    sync = None
+    if world > 1:
+        tensors = []
+        for name in ("context", "gsq_context", "cbias", "gsq_cbias"):
+            ptr, cnt = opt.device_ptr(name)
+            tensors.append(torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=torch.device("cuda", local_rank)))
+        sync = parallel.ContextSync(tensors)
+
+    def step(it):
+        c = opt.epoch(it)
+        if sync is not None and (it + 1) % args.sync_every == 0:
+            sync.sync()
+        return c
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    costs = []
+    for w in range(args.warmup):
+        costs.append(step(w))
+    fence()
+    kernel_ms = 0.0
+    launches = 0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        costs.append(step(args.warmup + k))
+        ms, nl = opt.last_kernel_ms()
+        kernel_ms += ms
+        launches += nl
+    fence()
+    dt = time.perf_counter() - t0
+
+    total_updates = n_local * args.steps
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        u = torch.tensor([float(total_updates)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        total_updates = float(u.item())
+
+    if rank == 0:
+        read_b, write_b = 16 * D + 28, 16 * D + 16
+        avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
+        ach = n_local * (read_b + write_b) / avg_kernel_s / 1e9          # GB/s, rank 0's kernel
+        out = {
+            "metric": "GloVe pair-updates/sec at dim=%d" % D,
+            "value": total_updates / dt,
+            "unit": "pair-updates/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "synthetic hub-heavy co-occurrence matrix (BASELINE C4 recipe scaled to %d GPU%s): "
+                                   "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, AdaGrad Hogwild, per-epoch device shuffle"
+                                   % (world, "s" if world > 1 else "", V, n_local, D, args.method),
+                       "vocab": V, "nnz_per_gpu": n_local, "dim": D, "cost": args.method,
+                       "parallelism": "rows sharded x%d, context replicated + sum-of-deltas all-reduce every %d step(s)"
+                                      % (world, args.sync_every) if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                         "traffic": None,
+                         "kernel": "k_adagrad_hogwild", "kernel_ms": avg_kernel_s * 1e3,
+                         "bytes_per_update": {"read": read_b, "write": write_b},
+                         "achieved_read": n_local * read_b / avg_kernel_s / 1e9,
+                         "frac_read": n_local * read_b / avg_kernel_s / 1e9 / 8000.0,
+                         "kernel_updates_per_s": n_local / avg_kernel_s},
+            "mean_cost_first_last": [costs[0] / n_local, costs[-1] / n_local],
+            "gen_seconds": t_gen,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, V, D, I, J, X, xmax)
+        print(json.dumps(out), flush=True)
+    opt.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""ctypes declarations for libgeglove.so -- one entry per symbol of include/geglove.h.
+
+No torch types cross this boundary: plain pointers and sizes only.  Loading the library
+does not touch the GPU; every computing entry point fails with GE_ERR_HIP when no gfx950
+device is present (there is no CPU fallback in the product).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgeglove.so")
+
+GE_OK, GE_ERR_ARG, GE_ERR_OOM, GE_ERR_HIP, GE_ERR_STATE, GE_ERR_OVERFLOW = 0, -1, -2, -3, -4, -5
+GE_COST_GLOVE, GE_COST_PGLOVE = 0, 1
+GE_OPT_ADAGRAD = 0
+GE_NORM_NONE, GE_NORM_UNITY, GE_NORM_COUNTS = 0, 1, 2
+GE_MODE_HOGWILD, GE_MODE_DETERMINISTIC = 0, 1
+GE_SHUFFLE_JAVA, GE_SHUFFLE_DEVICE, GE_SHUFFLE_NONE = 0, 1, 2
+(GE_STATE_FOCUS, GE_STATE_CONTEXT, GE_STATE_FBIAS, GE_STATE_CBIAS, GE_STATE_GSQ_FOCUS,
+ GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FBIAS, GE_STATE_GSQ_CBIAS) = range(8)
+STATE_NAMES = ("focus", "context", "fbias", "cbias", "gsq_focus", "gsq_context", "gsq_fbias", "gsq_cbias")
+
+# every symbol include/geglove.h declares (tests check the library exports all of them)
+SYMBOLS = (
+    "ge_glove_cfg_default", "ge_glove_create", "ge_glove_epoch", "ge_glove_extract_f32",
+    "ge_glove_extract_f64", "ge_glove_get_state", "ge_glove_set_state", "ge_glove_device_ptr",
+    "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_destroy",
+    "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_last_error", "ge_version", "ge_device_count",
+)
+
+
+class GloveCfg(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("dim", C.c_int32), ("nnz", C.c_int64),
+                ("cost", C.c_int32), ("opt", C.c_int32), ("learning_rate", C.c_float),
+                ("xmax", C.c_double), ("seed", C.c_int64), ("threads", C.c_int32),
+                ("mode", C.c_int32), ("shuffle", C.c_int32), ("device", C.c_int32),
+                ("stream", C.c_void_p), ("row_begin", C.c_int32), ("row_end", C.c_int32)]
+
+
+class Csr(C.Structure):
+    _fields_ = [("num_vertices", C.c_int32), ("ptr", C.POINTER(C.c_int64)),
+                ("idx", C.POINTER(C.c_int32)), ("weight", C.POINTER(C.c_float))]
+
+
+class BcaCfg(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("epsilon", C.c_double), ("directed", C.c_int32),
+                ("normalize", C.c_int32), ("device", C.c_int32), ("row_begin", C.c_int32),
+                ("row_end", C.c_int32)]
+
+
+class GeError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("geglove error %d: %s" % (status, message))
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """Loads libgeglove.so; raises (loudly) when the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libgeglove.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C graph-embeddings_amd/csrc`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    i32p, i64p, f32p, f64p = (C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_double))
+    vp = C.c_void_p
+    L.ge_glove_cfg_default.argtypes = [C.POINTER(GloveCfg)]; L.ge_glove_cfg_default.restype = None
+    L.ge_glove_create.argtypes = [C.POINTER(GloveCfg), i32p, i32p, f32p, C.POINTER(vp)]
+    L.ge_glove_epoch.argtypes = [vp, C.c_int32, f64p]
+    L.ge_glove_extract_f32.argtypes = [vp, f32p]
+    L.ge_glove_extract_f64.argtypes = [vp, f64p]
+    L.ge_glove_get_state.argtypes = [vp, C.c_int32, f32p, C.c_int64]
+    L.ge_glove_set_state.argtypes = [vp, C.c_int32, f32p, C.c_int64]
+    L.ge_glove_device_ptr.argtypes = [vp, C.c_int32, C.POINTER(vp), i64p]
+    L.ge_glove_get_perm.argtypes = [vp, i32p, C.c_int64]
+    L.ge_glove_rng_state.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.ge_glove_last_kernel_ms.argtypes = [vp, f32p, i32p]
+    L.ge_glove_destroy.argtypes = [vp]; L.ge_glove_destroy.restype = None
+    L.ge_bca_build.argtypes = [C.POINTER(Csr), C.POINTER(Csr), C.POINTER(BcaCfg), C.POINTER(vp)]
+    L.ge_coo_get.argtypes = [vp, i64p, C.POINTER(i32p), C.POINTER(i32p), C.POINTER(f32p), C.POINTER(i64p), f64p]
+    L.ge_coo_destroy.argtypes = [vp]; L.ge_coo_destroy.restype = None
+    L.ge_last_error.argtypes = []; L.ge_last_error.restype = C.c_char_p
+    L.ge_version.argtypes = []; L.ge_version.restype = C.c_char_p
+    L.ge_device_count.argtypes = []; L.ge_device_count.restype = C.c_int32
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if f.restype is C.c_int:      # default restype -> ge_status
+            f.restype = C.c_int32
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != GE_OK:
+        raise GeError(status, lib().ge_last_error().decode(errors="replace"))

@@ -1,0 +1,335 @@
+"""Host-side mirror of the reference's interfaces for the hot path (Python flavour, used by
+tests and bench.py; the C++ flavour with the `-c config.yml` CLI lives in ../host/).
+
+Every method that computes calls libgeglove.so through ctypes (capi.py).
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+from . import capi
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+class InvalidConfigurationException(Exception):
+    """Configuration.InvalidConfigurationException (J/util/config/Configuration.java:496-500)."""
+
+    def __init__(self, message):
+        super().__init__("Invalid configuration: " + message)
+
+
+class GloveCost:
+    """J/opt/GloveCost.java:5-21"""
+    kind = capi.GE_COST_GLOVE
+
+
+class PGloveCost:
+    """J/opt/PGloveCost.java:5-21"""
+    kind = capi.GE_COST_PGLOVE
+
+
+class Configuration:
+    """Tolerant stand-in for the SnakeYAML bean (J/util/config/Configuration.java).
+
+    Accepts the bean's keys AND the legacy keys present in the shipped YAMLs
+    (`bca.reverse`, `bca.predicates`, `similarity[].predicate`), which the Java bean of this
+    revision would reject.  New, optional keys live under `device:`:
+      mode: hogwild|deterministic   shuffle: java|device|none   seed: <long>   id: <ordinal>
+    """
+
+    def __init__(self, d=None):
+        d = dict(d or {})
+        self.graph = d.get("graph")
+        self.method = d.get("method")
+        self.dim = int(d.get("dim", 0) or 0)
+        self.threads = int(d.get("threads", 0) or 0)
+        self.weights = d.get("weights")
+        self.similarity = d.get("similarity")
+        self.bca = dict(d.get("bca") or {})
+        self.opt = dict(d.get("opt") or {})
+        self.pca = d.get("pca")
+        self.output = d.get("output")
+        self.device = dict(d.get("device") or {})
+
+    @staticmethod
+    def load(path):
+        """ConfigReader.load (J/util/read/ConfigReader.java:16-20)."""
+        import yaml
+        with open(path) as f:
+            return Configuration(yaml.safe_load(f))
+
+    @staticmethod
+    def check(config):
+        """Configuration.check (J/util/config/Configuration.java:478-494), same messages."""
+        bca = config.bca
+        has_bca = bool(bca) and float(bca.get("alpha", 0) or 0) > 0 and float(bca.get("epsilon", 0) or 0) > 0
+        out = config.output
+        has_out = out is not None and any(k in out and out[k] is not None for k in ("predicate", "blank", "uri", "literal"))
+        if not config.dim > 0:
+            raise InvalidConfigurationException("No dimension specified")
+        if not config.graph:
+            raise InvalidConfigurationException("No input graph specified")
+        if not config.method:
+            raise InvalidConfigurationException("Invalid method, choose one of: glove, pglove")
+        if not has_bca:
+            raise InvalidConfigurationException("Invalid BCA parameters, alpha and epsilon are mandatory")
+        if not has_out:
+            raise InvalidConfigurationException("Invalid output parameters, specify at least one group")
+
+    # bean getters used on the hot path
+    def getDim(self): return self.dim
+    def getThreads(self): return self.threads if self.threads != 0 else max((os.cpu_count() or 2) - 1, 1)   # :71-73
+    def getMethod(self): return self.method
+    def getAlpha(self): return float(self.bca["alpha"])
+    def getEpsilon(self): return float(self.bca["epsilon"])
+    def isDirected(self): return bool(self.bca.get("directed", False))
+    def getNormalize(self): return (self.bca.get("normalize") or "none")
+    def getTolerance(self): return float(self.opt.get("tolerance", 0.0))
+    def getMaxiter(self): return int(self.opt.get("maxiter", 0))
+    def getOptMethod(self): return self.opt.get("method", "adagrad")
+
+    def costFunction(self):
+        """Main.createOptimizer's first switch (J/Main.java:109-119)."""
+        m = (self.method or "").upper()
+        if m == "GLOVE":
+            return GloveCost()
+        if m == "PGLOVE":
+            return PGloveCost()
+        raise ValueError("Invalid cost function")
+
+
+class CooMatrix:
+    """CoOccurrenceMatrix (J/util/CoOccurrenceMatrix.java:6-17) over flat arrays.
+
+    cIdx_* index the matrix in PRE-shuffle order; the epoch permutation lives in the native
+    trainer (it is part of the RNG stream there, as in the reference).
+    """
+
+    def __init__(self, vocab_size, I, J, X, max_value, keys=None, types=None):
+        self._V = int(vocab_size)
+        self.I = np.ascontiguousarray(I, np.int32)
+        self.J = np.ascontiguousarray(J, np.int32)
+        self.X = np.ascontiguousarray(X, np.float32)
+        self._max = float(max_value)
+        self._keys, self._types = keys, types
+
+    def vocabSize(self): return self._V
+    def max(self): return self._max
+    def getKey(self, index): return self._keys[index] if self._keys is not None else str(index)
+    def getType(self, index): return int(self._types[index]) if self._types is not None else 0
+    def cIdx_I(self, i): return int(self.I[i])
+    def cIdx_J(self, j): return int(self.J[j])
+    def cIdx_C(self, i): return float(self.X[i])
+    def coOccurrenceCount(self): return int(self.I.shape[0])
+    def shuffle(self): pass  # owned by the native trainer
+
+
+def _csr_struct(V, csr, keep):
+    ptr, idx, w = csr
+    ptr = np.ascontiguousarray(ptr, np.int64); idx = np.ascontiguousarray(idx, np.int32)
+    w = np.ascontiguousarray(w, np.float32)
+    if ptr.shape[0] != V + 1:
+        raise ValueError("CSR ptr must have V+1 entries")
+    keep.extend([ptr, idx, w])
+    return capi.Csr(V, _p(ptr, C.c_int64), _p(idx, C.c_int32), _p(w, C.c_float))
+
+
+class BookmarkColoring(CooMatrix):
+    """`new BookmarkColoring(graph, config)` (J/bca/BookmarkColoring.java:32-120) on the device.
+
+    graph: dict(V=int, out=(ptr, idx, w), inn=(ptr, idx, w), keys=[...]?, types=[...]?) --
+    the weighted CSR/CSC that getIn/OutNeighborhoods + In/OutEdgeNeighborhoodAlgorithm yield.
+    """
+
+    _NORM = {"none": capi.GE_NORM_NONE, "unity": capi.GE_NORM_UNITY, "counts": capi.GE_NORM_COUNTS}
+
+    def __init__(self, graph, config, device=0, row_range=None):
+        V = int(graph["V"])
+        keep = []
+        out_s = _csr_struct(V, graph["out"], keep)
+        in_s = _csr_struct(V, graph["inn"], keep)
+        norm = self._NORM[str(config.getNormalize()).lower()]
+        rb, re = row_range if row_range else (0, 0)
+        cfg = capi.BcaCfg(config.getAlpha(), config.getEpsilon(), int(config.isDirected()), norm, device, rb, re)
+        h = C.c_void_p()
+        capi.check(capi.lib().ge_bca_build(C.byref(out_s), C.byref(in_s), C.byref(cfg), C.byref(h)))
+        try:
+            nnz = C.c_int64(); mx = C.c_double()
+            pI = C.POINTER(C.c_int32)(); pJ = C.POINTER(C.c_int32)(); pX = C.POINTER(C.c_float)()
+            pR = C.POINTER(C.c_int64)()
+            capi.check(capi.lib().ge_coo_get(h, C.byref(nnz), C.byref(pI), C.byref(pJ), C.byref(pX), C.byref(pR), C.byref(mx)))
+            n = nnz.value
+            I = np.ctypeslib.as_array(pI, shape=(max(n, 1),))[:n].copy()
+            J = np.ctypeslib.as_array(pJ, shape=(max(n, 1),))[:n].copy()
+            X = np.ctypeslib.as_array(pX, shape=(max(n, 1),))[:n].copy()
+            self.row_ptr = np.ctypeslib.as_array(pR, shape=(V + 1,)).copy()
+        finally:
+            capi.lib().ge_coo_destroy(h)
+        super().__init__(V, I, J, X, mx.value, graph.get("keys"), graph.get("types"))
+
+
+class Optimum:
+    """J/opt/Optimum.java:9-41"""
+
+    def __init__(self):
+        self.finalCost = 0.0
+        self.result = None
+        self.costHistory = []
+
+    def addIntermediaryResult(self, r): self.costHistory.append(r)
+    def getResult(self): return self.result
+    def setResult(self, r): self.result = r
+    def getFinalCost(self): return self.finalCost
+    def setFinalCost(self, c): self.finalCost = c
+
+
+_MODES = {"hogwild": capi.GE_MODE_HOGWILD, "deterministic": capi.GE_MODE_DETERMINISTIC}
+_SHUFFLES = {"java": capi.GE_SHUFFLE_JAVA, "device": capi.GE_SHUFFLE_DEVICE, "none": capi.GE_SHUFFLE_NONE}
+
+
+class Adagrad:
+    """`new Adagrad(coMatrix, config, costFunction)` + IOptimizer (J/opt/grad/Adagrad.java,
+    J/opt/Optimizer.java, J/opt/IOptimizer.java:6-11) over ge_glove_*.
+
+    Extra keyword arguments override config.device.* : mode, shuffle, seed, device, stream,
+    row_range (multi-GPU sharding), learning_rate.
+    """
+
+    def __init__(self, coMatrix, config, costFunction, **kw):
+        dev = dict(config.device)
+        dev.update({k: v for k, v in kw.items() if v is not None})
+        self.coMatrix, self.config, self.costFunction = coMatrix, config, costFunction
+        self.dimension = config.getDim()
+        self.vocabSize = coMatrix.vocabSize()
+        self.coCount = coMatrix.coOccurrenceCount()
+        self.numThreads = config.getThreads()
+        self.maxIterations = config.getMaxiter()
+        self.tolerance = config.getTolerance()
+        cfg = capi.GloveCfg()
+        capi.lib().ge_glove_cfg_default(C.byref(cfg))
+        cfg.vocab_size, cfg.dim, cfg.nnz = self.vocabSize, self.dimension, self.coCount
+        cfg.cost = costFunction.kind
+        cfg.opt = capi.GE_OPT_ADAGRAD
+        cfg.learning_rate = float(dev.get("learning_rate", 0.05))
+        cfg.xmax = coMatrix.max()
+        cfg.seed = int(dev.get("seed", 42))
+        cfg.threads = self.numThreads
+        cfg.mode = _MODES[str(dev.get("mode", "hogwild")).lower()]
+        cfg.shuffle = _SHUFFLES[str(dev.get("shuffle", "device")).lower()]
+        cfg.device = int(dev.get("id", dev.get("device", 0)))
+        cfg.stream = dev.get("stream", None)
+        rb, re = dev.get("row_range", (0, 0))
+        cfg.row_begin, cfg.row_end = rb, re
+        self._rows = (re - rb) if (rb, re) != (0, 0) else self.vocabSize
+        self._cfg = cfg
+        self._h = C.c_void_p()
+        I, J, X = coMatrix.I, coMatrix.J, coMatrix.X
+        capi.check(capi.lib().ge_glove_create(C.byref(cfg), _p(I, C.c_int32), _p(J, C.c_int32), _p(X, C.c_float),
+                                              C.byref(self._h)))
+
+    # -- IOptimizer -----------------------------------------------------------------------
+    def getName(self):
+        return "Adagrad"
+
+    def epoch(self, iteration=0):
+        """One loop body of Optimizer.optimize (shuffle + all jobs); returns the summed job cost."""
+        cost = C.c_double()
+        capi.check(capi.lib().ge_glove_epoch(self._h, iteration, C.byref(cost)))
+        return cost.value
+
+    def createJob(self, id, iteration):
+        """Natively one call runs every job of the epoch; job 0 carries it, the others are empty."""
+        if id == 0:
+            return lambda: self.epoch(iteration)
+        return lambda: 0.0
+
+    def optimize(self):
+        """Optimizer.optimize (J/opt/Optimizer.java:66-120): tolerance / history logic stays on the host."""
+        opt = Optimum()
+        finalCost = 0.0
+        prevCost = 0.0
+        for iteration in range(self.maxIterations):
+            localCost = self.epoch(iteration)
+            localCost = localCost / self.coCount if self.coCount else float("nan")
+            opt.addIntermediaryResult(localCost)
+            iterDiff = abs(prevCost - localCost)
+            prevCost = localCost
+            if iterDiff <= self.tolerance:
+                finalCost = localCost
+                break
+        opt.setResult(self.extractResult())
+        opt.setFinalCost(finalCost)
+        return opt
+
+    def extractResult(self):
+        out = np.empty(self.vocabSize * self.dimension, np.float64)
+        capi.check(capi.lib().ge_glove_extract_f64(self._h, _p(out, C.c_double)))
+        return out
+
+    def extractResultF32(self):
+        out = np.empty(self.vocabSize * self.dimension, np.float32)
+        capi.check(capi.lib().ge_glove_extract_f32(self._h, _p(out, C.c_float)))
+        return out
+
+    # -- state access (tests / multi-GPU sync) ---------------------------------------------------
+    def _count(self, which):
+        rows = self._rows if which in (capi.GE_STATE_FOCUS, capi.GE_STATE_FBIAS, capi.GE_STATE_GSQ_FOCUS,
+                                       capi.GE_STATE_GSQ_FBIAS) else self.vocabSize
+        per_row = self.dimension if which in (capi.GE_STATE_FOCUS, capi.GE_STATE_CONTEXT, capi.GE_STATE_GSQ_FOCUS,
+                                              capi.GE_STATE_GSQ_CONTEXT) else 1
+        return rows * per_row
+
+    def get_state(self, which):
+        if isinstance(which, str):
+            which = capi.STATE_NAMES.index(which)
+        n = self._count(which)
+        out = np.empty(n, np.float32)
+        capi.check(capi.lib().ge_glove_get_state(self._h, which, _p(out, C.c_float), n))
+        return out
+
+    def set_state(self, which, arr):
+        if isinstance(which, str):
+            which = capi.STATE_NAMES.index(which)
+        arr = np.ascontiguousarray(arr, np.float32).reshape(-1)
+        capi.check(capi.lib().ge_glove_set_state(self._h, which, _p(arr, C.c_float), arr.shape[0]))
+
+    def state(self):
+        return {n: self.get_state(i) for i, n in enumerate(capi.STATE_NAMES)}
+
+    def device_ptr(self, which):
+        if isinstance(which, str):
+            which = capi.STATE_NAMES.index(which)
+        p = C.c_void_p(); n = C.c_int64()
+        capi.check(capi.lib().ge_glove_device_ptr(self._h, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def perm(self):
+        out = np.empty(self.coCount, np.int32)
+        capi.check(capi.lib().ge_glove_get_perm(self._h, _p(out, C.c_int32), self.coCount))
+        return out
+
+    def rng_state(self):
+        s = C.c_uint64()
+        capi.check(capi.lib().ge_glove_rng_state(self._h, C.byref(s)))
+        return s.value
+
+    def last_kernel_ms(self):
+        ms = C.c_float(); n = C.c_int32()
+        capi.check(capi.lib().ge_glove_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            capi.lib().ge_glove_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

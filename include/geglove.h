@@ -1,0 +1,189 @@
+/*
+ * geglove.h -- C ABI of libgeglove.so, the MI355X (gfx950) implementation of the
+ * Phaken/graph-embeddings hot path:  BCA co-occurrence builder  ->  GloVe/pGloVe
+ * AdaGrad loop over the nonzero (i, j, X_ij) entries.
+ *
+ * The reference is pure Java with no native boundary; this header IS the
+ * boundary a maintainer would bind over JNI (INTEGRATION.md shows the Java side).  Each
+ * entry point cites the reference interface it replaces (J/ = src/main/java/org/uu/nl/embedding/).
+ *
+ * Conventions: plain C, no C++ types, no exceptions; every call returns ge_status
+ * (0 = ok, <0 = error) and leaves a message readable through ge_last_error() (thread local).
+ * The caller owns every host buffer passed in or filled; the library never keeps a host
+ * pointer after the call returns.  Handles are opaque and freed only by *_destroy.
+ * Calls on one handle are blocking and not re-entrant; distinct handles are independent.
+ * The library never calls exit()/abort().  There is NO CPU fallback: every entry point
+ * that computes needs a gfx950 device and fails with GE_ERR_HIP otherwise.
+ */
+#ifndef GEGLOVE_H
+#define GEGLOVE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t ge_status;
+enum {
+    GE_OK           =  0,
+    GE_ERR_ARG      = -1,   /* invalid argument (the Java path throws IllegalArgumentException / InvalidConfigurationException) */
+    GE_ERR_OOM      = -2,   /* host or device allocation failed */
+    GE_ERR_HIP      = -3,   /* HIP runtime error / no device */
+    GE_ERR_STATE    = -4,   /* call not valid in the handle's current state */
+    GE_ERR_OVERFLOW = -5    /* a per-bookmark work buffer overflowed (BCA frontier / row capacity) */
+};
+
+/* Configuration.EmbeddingMethod (J/util/config/Configuration.java:19-21): picks
+ * GloveCost (J/opt/GloveCost.java:5-21) or PGloveCost (J/opt/PGloveCost.java:5-21). */
+enum { GE_COST_GLOVE = 0, GE_COST_PGLOVE = 1 };
+/* Configuration.OptimizationMethod (J/util/config/Configuration.java:23-25); Main.createOptimizer
+ * (J/Main.java:121-130).  Only ADAGRAD is implemented this round. */
+enum { GE_OPT_ADAGRAD = 0 };
+/* Configuration.BCANormalization (J/util/config/Configuration.java:31-33). */
+enum { GE_NORM_NONE = 0, GE_NORM_UNITY = 1, GE_NORM_COUNTS = 2 };
+
+/* How the update loop is scheduled on the device.
+ * DETERMINISTIC: the exact semantics of the Java loop with `threads: T` where the T jobs of
+ *   Adagrad.createJob (J/opt/grad/Adagrad.java:42-98) run one after another in id order;
+ *   for T = 1 this IS the Java result, bit for bit (sequential fp32 dot, fp64 sqrt/div as in
+ *   :76-77, :88-89).  One wavefront; a parity / reproducibility mode, not a fast one.
+ * HOGWILD: the production mode.  Thousands of lane groups update the shared tables without
+ *   locks, exactly as the Java worker threads do (J/opt/Optimizer.java:27-28 are plain arrays),
+ *   fp32 arithmetic, wave-reduced dot. */
+enum { GE_MODE_HOGWILD = 0, GE_MODE_DETERMINISTIC = 1 };
+
+/* Order in which an epoch visits the nonzeros.
+ * JAVA:   CoOccurrenceMatrix.shuffle() = cumulative forward Fisher-Yates on one permutation,
+ *         drawn from the SAME java.util.Random stream that initialised the parameters
+ *         (J/opt/Optimizer.java:79; J/util/rnd/Permutation.java:21; ExtendedRandom.java:398-407).
+ * DEVICE: a fresh keyed bijection of [0, N) per epoch evaluated inside the kernel (no
+ *         permutation array, no host work) -- statistically equivalent, not the Java order.
+ * NONE:   matrix order (no shuffle). */
+enum { GE_SHUFFLE_JAVA = 0, GE_SHUFFLE_DEVICE = 1, GE_SHUFFLE_NONE = 2 };
+
+/* Parameter tables a caller can read or write (tests, checkpointing, multi-GPU sync). */
+enum {
+    GE_STATE_FOCUS = 0,        /* float[V*D]  Optimizer.focus         (J/opt/Optimizer.java:27) */
+    GE_STATE_CONTEXT = 1,      /* float[V*D]  Optimizer.context                                  */
+    GE_STATE_FBIAS = 2,        /* float[V]    Optimizer.fBias         (J/opt/Optimizer.java:28) */
+    GE_STATE_CBIAS = 3,        /* float[V]    Optimizer.cBias                                    */
+    GE_STATE_GSQ_FOCUS = 4,    /* float[V*D]  Adagrad.gradSqFocus     (J/opt/grad/Adagrad.java:16) */
+    GE_STATE_GSQ_CONTEXT = 5,  /* float[V*D]  Adagrad.gradSqContext                              */
+    GE_STATE_GSQ_FBIAS = 6,    /* float[V]    Adagrad.gradSqFBias     (J/opt/grad/Adagrad.java:17) */
+    GE_STATE_GSQ_CBIAS = 7,    /* float[V]    Adagrad.gradSqCBias                                */
+    GE_STATE_COUNT = 8
+};
+
+/* ------------------------------------------------------------------------------------------
+ * Trainer.  Replaces `new Adagrad(coMatrix, config, costFunction)` + IOptimizer
+ * (J/opt/IOptimizer.java:6-11; J/opt/Optimizer.java:34-64; J/opt/grad/Adagrad.java:19-34).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ge_glove ge_glove;
+
+typedef struct {
+    int32_t vocab_size;     /* V = coMatrix.vocabSize()          (J/opt/Optimizer.java:40)            */
+    int32_t dim;            /* D = config.getDim()               (J/opt/Optimizer.java:43); V*D < 2^31 as in Java */
+    int64_t nnz;            /* N = coMatrix.coOccurrenceCount()  (J/opt/Optimizer.java:42); N < 2^31 as in Java  */
+    int32_t cost;           /* GE_COST_*                                                               */
+    int32_t opt;            /* GE_OPT_*                                                                */
+    float   learning_rate;  /* 0.05f in the reference, hard coded (J/opt/Optimizer.java:26)            */
+    double  xmax;           /* coMatrix.max()                    (J/opt/GloveCost.java:19)             */
+    int64_t seed;           /* Configuration.setThreadLocalRandom(seed) (J/util/config/Configuration.java:161-163) */
+    int32_t threads;        /* config.getThreads(): job slicing N/T (+N%T on the last), J/opt/Optimizer.java:59-63.
+                               Used by DETERMINISTIC mode only; HOGWILD ignores it.  >= 1.             */
+    int32_t mode;           /* GE_MODE_*                                                               */
+    int32_t shuffle;        /* GE_SHUFFLE_*                                                            */
+    int32_t device;         /* HIP device ordinal                                                      */
+    void   *stream;         /* hipStream_t to launch on, or NULL for the device's null stream          */
+    int32_t row_begin;      /* multi-GPU row sharding: this handle owns focus rows      */
+    int32_t row_end;        /*   [row_begin,row_end); 0,0 = all rows.  I[] must lie inside the range.  */
+} ge_glove_cfg;
+
+/* Fills *cfg with the reference's defaults (adagrad, lr 0.05f, threads 1, HOGWILD, DEVICE shuffle). */
+void ge_glove_cfg_default(ge_glove_cfg *cfg);
+
+/* I, J, X: host arrays of length cfg->nnz in matrix (pre-shuffle) order, i.e. what
+ * cIdx_I/J/C(k) return before the first shuffle() (J/util/CoOccurrenceMatrix.java:12-14).
+ * Initialises focus/context/biases from java.util.Random(seed) in the reference's draw order
+ * (J/opt/Optimizer.java:50-57), gradSq* = 1 (J/opt/grad/Adagrad.java:27-33), identity permutation. */
+ge_status ge_glove_create(const ge_glove_cfg *cfg,
+                          const int32_t *I, const int32_t *J, const float *X,
+                          ge_glove **out);
+
+/* One pass of the body of Optimizer.optimize()'s loop (J/opt/Optimizer.java:79-94):
+ * shuffle, run all jobs, *cost_sum = sum over jobs of the job cost (what `localCost` holds at
+ * :94, BEFORE the division by coCount at :96).  `iteration` mirrors createJob's argument
+ * (unused by AdaGrad; it keys the DEVICE shuffle). */
+ge_status ge_glove_epoch(ge_glove *h, int32_t iteration, double *cost_sum);
+
+/* Optimizer.extractResult (J/opt/Optimizer.java:129-140): out[k] = (focus[k]+context[k])/2.
+ * _f32 keeps fp32; _f64 widens as the Java double[] does. out has V*D elements (row-major). */
+ge_status ge_glove_extract_f32(ge_glove *h, float *out);
+ge_status ge_glove_extract_f64(ge_glove *h, double *out);
+
+/* Copy one GE_STATE_* table device->host / host->device (count = number of floats). */
+ge_status ge_glove_get_state(ge_glove *h, int32_t which, float *out, int64_t count);
+ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_t count);
+/* Raw device pointer of a table (for zero-copy wrapping by the host runtime, e.g. the
+ * torch.distributed/RCCL all-reduce of the context factors). Valid until destroy. */
+ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *count);
+
+/* Current permutation (GE_SHUFFLE_JAVA only) and java.util.Random state, for parity tests. */
+ge_status ge_glove_get_perm(ge_glove *h, int32_t *out, int64_t count);
+ge_status ge_glove_rng_state(ge_glove *h, uint64_t *state);
+
+/* Device time of the last epoch's update kernel(s), measured with hipEvents on the launch
+ * stream, in milliseconds; *launches = number of kernel launches it covered. */
+ge_status ge_glove_last_kernel_ms(ge_glove *h, float *ms, int32_t *launches);
+
+void ge_glove_destroy(ge_glove *h);
+
+/* ------------------------------------------------------------------------------------------
+ * Co-occurrence builder.  Replaces `new BookmarkColoring(graph, config)`
+ * (J/bca/BookmarkColoring.java:32-120) once the host has flattened the grph graph into
+ * weighted CSR (out-neighbours) + CSC (in-neighbours), which is what
+ * In/OutEdgeNeighborhoodAlgorithm.compute + getIn/OutNeighborhoods produce
+ * (J/bca/BookmarkColoring.java:49-52; J/convert/util/EdgeNeighborhoodAlgorithm.java:22-33).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct ge_coo ge_coo;
+
+typedef struct {
+    int32_t        num_vertices;   /* V */
+    const int64_t *ptr;            /* V+1 offsets */
+    const int32_t *idx;            /* neighbour ids, unique within a row, in grph neighbour order */
+    const float   *weight;         /* edge weight per neighbour (NumericalProperty.getValueAsFloat) */
+} ge_csr;
+
+typedef struct {
+    double  alpha;       /* bca.alpha   (J/util/config/Configuration.java:322) */
+    double  epsilon;     /* bca.epsilon */
+    int32_t directed;    /* bca.directed: 1 = DirectedWeighted (forward + forced reverse pass), 0 = UndirectedWeighted */
+    int32_t normalize;   /* GE_NORM_* */
+    int32_t device;      /* HIP device ordinal */
+    int32_t row_begin;   /* bookmarks [row_begin,row_end) only; 0,0 = all (multi-GPU sharding) */
+    int32_t row_end;
+} ge_bca_cfg;
+
+/* Runs one BCA job per bookmark (BCAJob.call, J/bca/util/BCAJob.java:31-36) on the device and
+ * assembles the COO in ascending bookmark order with each row in java.util.HashMap iteration
+ * order -- the order BookmarkColoring produces with `threads: 1`. */
+ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_bca_cfg *cfg, ge_coo **result);
+
+/* Host views into the result (owned by the handle, valid until ge_coo_destroy):
+ * I/J/X = coOccurrenceIdx_I/_J/Values (J/bca/BookmarkColoring.java:23-25), *max = max() (:153),
+ * row_ptr[V+1] = first entry of each bookmark.  Any out pointer may be NULL. */
+ge_status ge_coo_get(const ge_coo *c, int64_t *nnz, const int32_t **I, const int32_t **J,
+                     const float **X, const int64_t **row_ptr, double *max);
+void ge_coo_destroy(ge_coo *c);
+
+/* ------------------------------------------------------------------------------------------ */
+const char *ge_last_error(void);     /* message of the calling thread's last failed call */
+const char *ge_version(void);
+/* Number of visible HIP devices that are gfx950; <0 on HIP error. Does not compute. */
+int32_t ge_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEGLOVE_H */

@@ -1,0 +1,159 @@
+"""GPU parity of the AdaGrad trainer (ge_glove_*) against the CPU restatement (oracle/).
+
+Bars (BASELINE.json north_star):
+  * deterministic mode: BIT-EXACT vs the oracle on identical seeds (fp32 tables, fp64 cost),
+    which also satisfies the north-star vector tolerance of <= 1e-4.
+  * Hogwild mode: conflict-free batches must match within 2e-6 relative (only the dot-product
+    reduction order and fp32-vs-fp64 sqrt/div differ); racy epochs are compared on the cost
+    trajectory (tolerance stated per test).
+The oracle itself is "parity unpinned" w.r.t. Java (no JDK, no reference fixtures).
+"""
+import numpy as np
+import pytest
+
+import geglove
+from geglove import capi, synth
+import oracle as O
+from helpers import make_config, cost_kind, assert_state_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def _det(V, D, I, J, X, xmax, method, threads=1, seed=42, shuffle="java"):
+    cfg = make_config(D, method, threads=threads, mode="deterministic", shuffle=shuffle, seed=seed)
+    m = geglove.CooMatrix(V, I, J, X, xmax)
+    return geglove.Adagrad(m, cfg, cfg.costFunction())
+
+
+@pytest.mark.parametrize("method", ["glove", "pglove"])
+@pytest.mark.parametrize("D", [1, 3, 50, 100, 200])
+def test_init_matches_java_draw_order(gpu, method, D):
+    V = 37
+    I, J, X, xmax = synth.synthetic_coo(V, 200, seed=5)
+    opt = _det(V, D, I, J, X, xmax, method)
+    ora = O.Glove(V, D, I, J, X, xmax, cost_kind(method), seed=42, threads=1)
+    assert_state_equal(opt.state(), ora, what="init")
+    assert opt.rng_state() == ora.rng_state
+
+
+@pytest.mark.parametrize("method", ["glove", "pglove"])
+@pytest.mark.parametrize("D", [3, 50, 100, 200, 300])
+def test_deterministic_epochs_bit_exact(gpu, method, D):
+    V, N = 300, 4000
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=9)
+    opt = _det(V, D, I, J, X, xmax, method)
+    ora = O.Glove(V, D, I, J, X, xmax, cost_kind(method), seed=42, threads=1)
+    n = len(I)
+    for it in range(3):
+        c_dev = opt.epoch(it) / n
+        c_ora = ora.epoch()
+        assert np.array_equal(opt.perm(), ora.perm), "Java Fisher-Yates permutation differs at epoch %d" % it
+        assert opt.rng_state() == ora.rng_state
+        assert c_dev == c_ora, "epoch %d cost %r vs oracle %r" % (it, c_dev, c_ora)
+        assert_state_equal(opt.state(), ora, what="epoch %d" % it)
+    np.testing.assert_array_equal(opt.extractResult(), ora.extract().reshape(-1))
+
+
+@pytest.mark.parametrize("threads", [2, 7])
+def test_deterministic_job_slicing(gpu, threads):
+    """T jobs run one after another: slices N/T (+N%T on the last), one fp32 cost per job."""
+    V, N, D = 120, 1501, 20
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=3)
+    opt = _det(V, D, I, J, X, xmax, "glove", threads=threads)
+    ora = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=threads)
+    for it in range(2):
+        assert opt.epoch(it) / len(I) == ora.epoch(race=False)
+    assert_state_equal(opt.state(), ora, what="T=%d" % threads)
+
+
+def test_optimize_loop_matches_oracle(gpu):
+    """Optimizer.optimize: history, tolerance stop, finalCost only on convergence."""
+    V, N, D = 150, 2000, 16
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=21)
+    cfg = make_config(D, "pglove", maxiter=6, tolerance=1e-3, mode="deterministic", shuffle="java", seed=7)
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+    res = opt.optimize()
+    ora = O.Glove(V, D, I, J, X, xmax, O.COST_PGLOVE, seed=7, threads=1)
+    hist, fin = ora.optimize(6, 1e-3)
+    assert res.costHistory == list(hist)
+    assert res.getFinalCost() == fin
+    np.testing.assert_array_equal(res.getResult(), ora.extract().reshape(-1))
+
+
+def test_vector_tolerance_dblp_like_D200(gpu):
+    """BASELINE config C3 stand-in: DBLP-like graph -> (oracle) BCA -> D=200 AdaGrad; vectors <= 1e-4."""
+    g = synth.dblp_like_graph(300, 450, 8)
+    coo = O.bca_build(g["V"], g["out"], g["inn"], 0.1, 1e-3, True, O.NORM_NONE)
+    V, D = g["V"], 200
+    opt = _det(V, D, coo["I"], coo["J"], coo["X"], coo["max"], "pglove")
+    ora = O.Glove(V, D, coo["I"], coo["J"], coo["X"], coo["max"], O.COST_PGLOVE, seed=42, threads=1)
+    for it in range(2):
+        opt.epoch(it); ora.epoch()
+    dev = opt.extractResult(); ref = ora.extract().reshape(-1)
+    assert np.max(np.abs(dev - ref)) <= 1e-4          # north-star tolerance
+    assert np.array_equal(dev, ref)                   # and in fact bit-exact
+
+
+@pytest.mark.parametrize("method", ["glove", "pglove"])
+@pytest.mark.parametrize("D", [2, 5, 50, 100, 200, 300, 512])
+def test_hogwild_conflict_free_batch(gpu, method, D):
+    """All i distinct, all j distinct: the racy kernel has one possible result."""
+    V = 5000
+    I, J, X = synth.conflict_free_batch(V, 4096, seed=D)
+    xmax = 0.2
+    cfg = make_config(D, method, mode="hogwild", shuffle="device", seed=42)
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+    st = opt.state()
+    ref = {k: (v.reshape(V, D).copy() if v.size == V * D else v.copy()) for k, v in st.items()}
+    ref = {k: np.ascontiguousarray(v, np.float32) for k, v in ref.items()}
+    job_cost = O.adagrad_job(D, I, J, X, xmax, cost_kind(method), ref)
+    cost = opt.epoch(0)
+    assert cost == pytest.approx(float(job_cost), rel=2e-4)      # oracle accumulates the job cost in fp32
+    assert_state_equal(opt.state(), ref, exact=False, rtol=2e-6, atol=1e-9, what="hogwild D=%d" % D)
+
+
+def test_hogwild_visits_every_nonzero_once(gpu):
+    """DEVICE shuffle is a bijection: with lr=0-like no-op we cannot see it, so count through gradSq
+    of the biases: each update adds wc^2 > 0 exactly once per (i,j) on a conflict-free batch."""
+    V, D = 3000, 8
+    I, J, X = synth.conflict_free_batch(V, 2500, seed=77)
+    cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=1)
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, 0.2), cfg, cfg.costFunction())
+    opt.epoch(0)
+    g = opt.get_state("gsq_fbias")
+    touched = np.nonzero(g != 1.0)[0]
+    assert np.array_equal(np.sort(touched), np.sort(I))
+
+
+@pytest.mark.parametrize("method", ["glove", "pglove"])
+def test_hogwild_cost_trajectory_tracks_oracle(gpu, method):
+    """Racy epochs on hub-heavy data: per-epoch mean cost within 5 % of the sequential oracle."""
+    V, N, D = 2000, 60000, 50
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
+    cfg = make_config(D, method, mode="hogwild", shuffle="device", seed=42)
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+    ora = O.Glove(V, D, I, J, X, xmax, cost_kind(method), seed=42, threads=1)
+    n = len(I)
+    dev = [opt.epoch(it) / n for it in range(5)]
+    ref = [ora.epoch() for _ in range(5)]
+    assert np.all(np.isfinite(dev))
+    assert dev[-1] < dev[0]
+    np.testing.assert_allclose(dev, ref, rtol=0.05)
+
+
+def test_empty_matrix_and_bad_arguments(gpu):
+    cfg = make_config(4, "glove", mode="hogwild")
+    V = 5
+    opt = geglove.Adagrad(geglove.CooMatrix(V, np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.float32), 1.0),
+                          cfg, cfg.costFunction())
+    assert opt.epoch(0) == 0.0
+    assert opt.extractResultF32().shape == (V * 4,)
+    with pytest.raises(geglove.GeError) as e:
+        geglove.Adagrad(geglove.CooMatrix(V, [0], [9], [0.1], 1.0), cfg, cfg.costFunction())
+    assert e.value.status == capi.GE_ERR_ARG
+    with pytest.raises(geglove.GeError):
+        geglove.Adagrad(geglove.CooMatrix(V, [0], [1], [0.1], 1.0), make_config(0), GloveCostless())
+
+
+class GloveCostless:
+    kind = capi.GE_COST_GLOVE
