@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--method", default="glove", choices=["glove", "pglove"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--hot", default="auto", choices=["auto", "none", "all"])
     ap.add_argument("--sync-every", type=int, default=1, help="steps between context all-reduces (N>1)")
     return ap.parse_args()
 
@@ -102,7 +103,7 @@ def main():
         "bca": {"alpha": 0.1, "epsilon": 1e-3, "directed": True},
         "opt": {"method": "adagrad", "tolerance": 0, "maxiter": args.steps},
         "output": {"uri": []},
-        "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank,
+        "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot,
                    "row_range": rows if world > 1 else (0, 0)}})
     opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
 

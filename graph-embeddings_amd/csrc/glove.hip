@@ -33,7 +33,10 @@ struct GloveParams {
     const int32_t *I, *J;
     const float *X;
     const int32_t *perm;
+    const double *L;       // Hogwild: per-nonzero log term  (k_cost_terms)
+    const float *W;        // Hogwild: per-nonzero weight
     double *cost_out;      // Hogwild: one double accumulator
+    unsigned long long *queue;   // Hogwild: next chunk to hand out (zeroed before every launch)
     double xmax;
     int64_t N;
     int32_t D;
@@ -48,13 +51,32 @@ struct GloveParams {
 // GloveCost:  ic = s + (fB+cB) - log(X);  wc = (X > max) ? ic : (float)pow(X/max, 0.75) * ic
 // PGloveCost: ic = s + (fB+cB) - log(X/(1-X)) [fp32 division];  wc = X * ic
 // Both reduce to  ic = (float)((double)s + ((double)(fB+cB) - l)),  wc = w * ic.
+// EXACT = the deterministic kernel (libm pow, as FastMath.pow in GloveCost.java:19); the Hogwild
+// kernel forms r^0.75 as sqrt(r)*sqrt(sqrt(r)) in fp64 (<= 2 ulp of fp64 before the fp32
+// narrowing, far inside its tolerance) because pow() alone costs ~60 VGPRs of occupancy.
+template <bool EXACT>
 __device__ __forceinline__ void cost_terms(int kind, float x, double xmax, double &l, float &w) {
     if (kind == GE_COST_GLOVE) {
         l = log((double)x);
-        w = ((double)x > xmax) ? 1.0f : (float)pow((double)x / xmax, 0.75);
+        const double r = (double)x / xmax;
+        if (EXACT) w = ((double)x > xmax) ? 1.0f : (float)pow(r, 0.75);
+        else { const double q = sqrt(r); w = ((double)x > xmax) ? 1.0f : (float)(q * sqrt(q)); }
     } else {
         l = log((double)(x / (1.0f - x)));
         w = x;
+    }
+}
+
+// The Hogwild kernel reads (l, w) instead of X: X never changes, so the fp64 log / sqrt run once
+// per nonzero at create time (one lane per nonzero) instead of once per update, and the update
+// kernel keeps its registers for rows in flight.  +8 bytes read per update (0.1 % at D=200).
+__global__ void k_cost_terms(const float *X, int64_t n, int kind, double xmax, double *L, float *W) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; k < n; k += stride) {
+        double l; float w;
+        cost_terms<false>(kind, X[k], xmax, l, w);
+        L[k] = l; W[k] = w;
     }
 }
 
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(64) void k_adagrad_exact(GloveParams p, int64_t k_b
         float ic = 0.0f;
         for (int32_t d = 0; d < D; ++d) ic = ic + s_prod[d];
         double l; float w;
-        cost_terms(p.cost_kind, x, p.xmax, l, w);
+        cost_terms<true>(p.cost_kind, x, p.xmax, l, w);
         ic = (float)((double)ic + ((double)(p.fbias[bu] + p.cbias[bv]) - l));
         float wc = w * ic;
         cost = (float)((double)cost + (0.5 * (double)wc) * (double)ic);
@@ -162,12 +184,21 @@ __global__ __launch_bounds__(64) void k_adagrad_exact(GloveParams p, int64_t k_b
 }
 
 // ---- Hogwild kernel -----------------------------------------------------------------------
-// Block = 256 threads = 256/G lane groups; a group of G lanes owns one nonzero at a time
-// (G = 16: one DPP row, four nonzeros in flight per wavefront).  Per tile of 256 nonzeros the
-// block first stages (i, j, w, l) in LDS -- one nonzero per lane, so the fp64 log/pow of the cost
-// function cost 1/64 of a wave-instruction per nonzero -- then each group walks its share:
-// 16-byte coalesced loads of the four rows, fp32 dot reduced across the group, fused AdaGrad
-// update, plain (lock-free) stores.  Rows are read once and written once per update.
+// One wavefront = one sequential worker, like one Java pool thread (Adagrad.createJob walks its
+// slice in order).  A worker takes a chunk of 128 nonzeros of the epoch order, sorts it by column
+// in registers (bitonic network, no LDS, no barrier) and walks it sequentially:
+//   * a RUN of equal j keeps context[j], gradSqContext[j], cBias[j], gradSqCBias[j] in registers --
+//     loaded once, updated in place with exact sequential semantics inside the run, written once;
+//   * the focus side of every nonzero is gathered with 16-byte coalesced buffer loads (row base
+//     in SGPRs, hardware bounds check masks the lanes past D), the fp32 dot is wave-reduced, the
+//     fused AdaGrad update is written straight back; the next nonzero's focus rows are
+//     requested before the current one is computed.
+// Workers never lock (Hogwild).  ~10^4 workers are in flight where the JVM has <= #cores, so for
+// HOT columns (hub nodes that sit in a large share of the nonzeros) a plain read-modify-write
+// would lose most concurrent updates and training stalls (measured): their runs read
+// the row with agent-coherent (sc1) loads and publish the run's DELTA with float atomic adds.
+// Run-combining is what makes that affordable: same-address atomics serialise at ~25 ns per
+// cache line at the memory side.
 template <int VW> struct Vec;
 template <> struct Vec<4> { using T = float4; };
 template <> struct Vec<2> { using T = float2; };
@@ -178,157 +209,329 @@ template <> __device__ __forceinline__ float &comp<4>(float4 &v, int c) { return
 template <> __device__ __forceinline__ float &comp<2>(float2 &v, int c) { return (&v.x)[c]; }
 template <> __device__ __forceinline__ float &comp<1>(float &v, int) { return v; }
 
-constexpr int HW_TILE = 256;
+typedef int   ge_i4 __attribute__((ext_vector_type(4)));
+typedef int   ge_i2 __attribute__((ext_vector_type(2)));
 
-template <int G, int VW, int NCH>
-__global__ __launch_bounds__(256) void k_adagrad_hogwild(GloveParams p, int64_t k_begin, int64_t k_end) {
-    using V = typename Vec<VW>::T;
-    constexpr int NG = 256 / G;
-    __shared__ int32_t s_i[HW_TILE], s_j[HW_TILE];
-    __shared__ float   s_w[HW_TILE];
-    __shared__ double  s_l[HW_TILE];
-    __shared__ double  s_cost[256 / 64];
+constexpr int AUX_PLAIN = 0;
+constexpr int AUX_SC1 = 16;     // agent-coherent: bypasses the CU's L1, sees memory-side atomics
 
-    const int tid = threadIdx.x;
-    const int gl = tid % G;          // lane within the group
-    const int grp = tid / G;
+template <int VW, int AUX>
+__device__ __forceinline__ typename Vec<VW>::T buf_load(__amdgpu_buffer_rsrc_t rs, int off) {
+    typename Vec<VW>::T r;
+    if constexpr (VW == 4) { ge_i4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, AUX); __builtin_memcpy(&r, &v, 16); }
+    else if constexpr (VW == 2) { ge_i2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, AUX); __builtin_memcpy(&r, &v, 8); }
+    else { int v = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, AUX); __builtin_memcpy(&r, &v, 4); }
+    return r;
+}
+template <int VW>
+__device__ __forceinline__ void buf_store(typename Vec<VW>::T val, __amdgpu_buffer_rsrc_t rs, int off) {
+    if constexpr (VW == 4) { ge_i4 v; __builtin_memcpy(&v, &val, 16); __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0); }
+    else if constexpr (VW == 2) { ge_i2 v; __builtin_memcpy(&v, &val, 8); __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0); }
+    else { int v; __builtin_memcpy(&v, &val, 4); __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0); }
+}
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t rs, int off, bool coherent) {
+    int v = coherent ? __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, AUX_SC1)
+                     : __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, AUX_PLAIN);
+    return __builtin_bit_cast(float, v);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// Sum over the 64 lanes, result in every lane.  Four DPP adds reduce each row of 16 lanes
+// (quad swaps, half-row mirror, row mirror), then the four row sums are read through SGPRs.
+__device__ __forceinline__ float dpp_add(float v, int ctrl_sel) {
+    const int iv = __builtin_bit_cast(int, v);
+    int r;
+    switch (ctrl_sel) {
+        case 0:  r = __builtin_amdgcn_update_dpp(0, iv, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
+        case 1:  r = __builtin_amdgcn_update_dpp(0, iv, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+        case 2:  r = __builtin_amdgcn_update_dpp(0, iv, 0x141, 0xF, 0xF, false); break;   // row_half_mirror
+        default: r = __builtin_amdgcn_update_dpp(0, iv, 0x140, 0xF, 0xF, false); break;   // row_mirror
+    }
+    return v + __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = dpp_add(v, 0); v = dpp_add(v, 1); v = dpp_add(v, 2); v = dpp_add(v, 3);
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+constexpr int RUN_CHUNK = 128;            // nonzeros per worker chunk (2 per lane)
+constexpr int KEY_PAD = 0x7FFFFFFF;       // sorts last; marks the unused tail of the last chunk
+
+template <int VW, int NCH>
+__global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_begin, int64_t k_end, int32_t V, int32_t n_workers) {
+    using VT = typename Vec<VW>::T;
+    const int lane = threadIdx.x & 63;
     const int32_t D = p.D;
+    const uint32_t row_bytes = (uint32_t)D * 4u;
     const float lr = p.lr;
+    const int wave = rfl((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (wave >= n_workers) return;          // workers pull chunks of the epoch order from one queue
+    const int64_t n = k_end - k_begin;
+    const int64_t n_chunks = (n + RUN_CHUNK - 1) / RUN_CHUNK;
+    __shared__ float s_tr[4][2][NCH * 64 * VW];       // per-wave strip for the atomic flush (no block barrier)
+    const uint32_t bias_bytes = (uint32_t)((uint64_t)V * 4u > 0xFFFFFFFFull ? 0xFFFFFFFFull : (uint64_t)V * 4u);
+    // the focus-side pointers are rebased by the owned row range; bias tables are addressed by global row id
+    const __amdgpu_buffer_rsrc_t rs_cb = make_rsrc(p.cbias, bias_bytes), rs_gcb = make_rsrc(p.gscb, bias_bytes);
     double cost_acc = 0.0;
 
-    const int64_t n_tiles = (k_end - k_begin + HW_TILE - 1) / HW_TILE;
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        {   // stage: one nonzero per lane
-            const int64_t k = k_begin + tile * HW_TILE + tid;
-            int32_t bu = -1, bv = 0; float w = 0.0f; double l = 0.0;
+    for (;;) {
+        unsigned long long ticket = 0;
+        if (lane == 0) ticket = atomicAdd(p.queue, 1ull);
+        const int64_t chunk = ((int64_t)(unsigned)rfl((int)(ticket >> 32)) << 32) | (unsigned)rfl((int)(ticket & 0xFFFFFFFFull));
+        if (chunk >= n_chunks) break;
+        // ---- stage: two nonzeros per lane ------------------------------------------------------
+        int32_t key[2], slot[2], ii[2];
+        float ww[2];
+        double ll[2];
+        const int64_t base = k_begin + chunk * RUN_CHUNK;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t k = base + q * 64 + lane;
+            key[q] = KEY_PAD; ii[q] = 0; ww[q] = 0.0f; ll[q] = 0.0;
+            slot[q] = q * 64 + lane;
             if (k < k_end) {
                 const int64_t idx = map_index(p, k);
-                bu = p.I[idx]; bv = p.J[idx];
-                cost_terms(p.cost_kind, p.X[idx], p.xmax, l, w);
+                key[q] = p.J[idx]; ii[q] = p.I[idx]; ww[q] = p.W[idx]; ll[q] = p.L[idx];
             }
-            s_i[tid] = bu; s_j[tid] = bv; s_w[tid] = w; s_l[tid] = l;
         }
-        __syncthreads();
-        for (int e = grp; e < HW_TILE; e += NG) {
-            const int32_t bu = s_i[e];
-            if (bu < 0) break;                       // tail of the last tile
-            const int32_t bv = s_j[e];
-            const float w = s_w[e];
-            const double l = s_l[e];
-            float *foc = p.focus + (int64_t)bu * D, *ctx = p.context + (int64_t)bv * D;
-            float *g1s = p.gsf + (int64_t)bu * D,   *g2s = p.gsc + (int64_t)bv * D;
+        const int n_valid = rfl((int)((k_end - base) < RUN_CHUNK ? (k_end - base) : RUN_CHUNK));
 
-            V f[NCH], c[NCH], gf[NCH], gc[NCH];
-            float part = 0.0f;
+        // ---- bitonic sort of (key, slot) over positions pos = q*64 + lane ---------------------
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                const int off = (gl + q * G) * VW;
-                if (off < D) {
-                    f[q]  = *reinterpret_cast<const V *>(foc + off);
-                    c[q]  = *reinterpret_cast<const V *>(ctx + off);
-                    gf[q] = *reinterpret_cast<const V *>(g1s + off);
-                    gc[q] = *reinterpret_cast<const V *>(g2s + off);
+        for (int k2 = 2; k2 <= RUN_CHUNK; k2 <<= 1) {
+#pragma unroll
+            for (int j2 = k2 >> 1; j2 >= 1; j2 >>= 1) {
+                if (j2 == 64) {
+                    if (key[0] > key[1] || (key[0] == key[1] && slot[0] > slot[1])) {   // k2 == 128: ascending everywhere
+                        const int32_t tk = key[0], ts = slot[0];
+                        key[0] = key[1]; slot[0] = slot[1]; key[1] = tk; slot[1] = ts;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int pos = q * 64 + lane;
+                        const int32_t pk = __shfl_xor(key[q], j2, 64);
+                        const int32_t ps = __shfl_xor(slot[q], j2, 64);
+                        const bool asc = (pos & k2) == 0;
+                        const bool lower = (lane & j2) == 0;
+                        // total order (key, slot): the walk order is the STABLE sort of the chunk by column
+                        const bool p_less = pk < key[q] || (pk == key[q] && ps < slot[q]);
+                        const bool take = (asc == lower) ? p_less : !p_less;
+                        if (take) { key[q] = pk; slot[q] = ps; }
+                    }
                 }
             }
-            const float fb = p.fbias[bu], cb = p.cbias[bv];
-            const float gfb = p.gsfb[bu], gcb = p.gscb[bv];
+        }
+
+        // ---- sequential walk ---------------------------------------------------------------------
+        // Software pipeline: while nonzero `pos` is computed, the focus rows of pos+1 and (when the
+        // column changes there) its context rows are already in flight.  They are requested BEFORE
+        // this nonzero's stores, so waiting for them never waits for a store to retire.
+        int32_t cur_key = KEY_PAD;
+        VT c[NCH], gc[NCH], c0[NCH], gc0[NCH];
+        float cb = 0.0f, gcb = 0.0f;
+        __amdgpu_buffer_rsrc_t rs_c = rs_cb, rs_gc = rs_cb;
+        bool inr[NCH];                      // lane holds real elements of the row (D % VW == 0)
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) inr[q] = (lane + q * 64) * VW < D;
+
+        auto close_run = [&]() {
+            const bool hot = cur_key < 0;
+            const int32_t bv = hot ? ~cur_key : cur_key;
+            if (!hot) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    buf_store<VW>(c[q], rs_c, (lane + q * 64) * VW * 4);
+                    buf_store<VW>(gc[q], rs_gc, (lane + q * 64) * VW * 4);
+                }
+                if (lane == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cb), rs_cb, bv * 4, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gcb), rs_gcb, bv * 4, 0, 0);
+                }
+            } else {
+                // Publish the run's delta with float atomics.  Lane L holds elements [VW*L, VW*L+VW);
+                // staged through this wave's LDS strip so that every atomic wave-instruction covers 64
+                // CONSECUTIVE dwords (256 B = four 64-B memory-side requests instead of sixteen).
+                float *tr_c = s_tr[threadIdx.x >> 6][0], *tr_g = s_tr[threadIdx.x >> 6][1];
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    VT dc, dg;
+#pragma unroll
+                    for (int t = 0; t < VW; ++t) {
+                        comp<VW>(dc, t) = comp<VW>(c[q], t) - comp<VW>(c0[q], t);
+                        comp<VW>(dg, t) = comp<VW>(gc[q], t) - comp<VW>(gc0[q], t);
+                    }
+                    *reinterpret_cast<VT *>(tr_c + (lane + q * 64) * VW) = dc;
+                    *reinterpret_cast<VT *>(tr_g + (lane + q * 64) * VW) = dg;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int k = 0; k < NCH * VW; ++k) {
+                    const int e = lane + k * 64;          // element index; past D the buffer check drops it
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_c[e], rs_c, e * 4, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_g[e], rs_gc, e * 4, 0, 0);
+                }
+                __builtin_amdgcn_wave_barrier();
+                // The bias takes AdaGrad steps WITHOUT a learning rate (Adagrad.java:88-89): one run
+                // alone already moves it most of the way, so concurrent runs must not add up.  The
+                // scalars are merged last-writer-wins (what the Java race does), written through (sc1)
+                // so that the other XCDs' coherent loads see them.
+                if (lane == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cb), rs_cb, bv * 4, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gcb), rs_gcb, bv * 4, 0, AUX_SC1);
+                }
+            }
+        };
+
+        // decoded next nonzero + its prefetched rows
+        int32_t n_bu = 0, n_key = KEY_PAD; float n_w = 0.0f; double n_l = 0.0;
+        VT nf[NCH], ngf[NCH]; float n_fb = 0.0f, n_gfb = 0.0f;
+        VT cN[NCH], gcN[NCH]; float cbN = 0.0f, gcbN = 0.0f;
+        __amdgpu_buffer_rsrc_t rsN_c = rs_cb, rsN_gc = rs_cb;
+        auto decode = [&](int pos) {
+            const int q = pos >> 6, ln = pos & 63;
+            n_key = __builtin_amdgcn_readlane(q ? key[1] : key[0], ln);
+            const int sl = __builtin_amdgcn_readlane(q ? slot[1] : slot[0], ln);
+            const int sq = sl >> 6, sln = sl & 63;
+            n_bu = __builtin_amdgcn_readlane(sq ? ii[1] : ii[0], sln);
+            n_w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq ? ww[1] : ww[0]), sln));
+            const long long lb = __builtin_bit_cast(long long, sq ? ll[1] : ll[0]);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(lb & 0xFFFFFFFFll), sln);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(lb >> 32), sln);
+            n_l = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+        };
+        auto request_focus = [&]() {
+            const __amdgpu_buffer_rsrc_t rf = make_rsrc(p.focus + (int64_t)n_bu * D, row_bytes);
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.gsf + (int64_t)n_bu * D, row_bytes);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
-                const int off = (gl + q * G) * VW;
-                if (off < D) {
+                nf[q]  = buf_load<VW, AUX_PLAIN>(rf, (lane + q * 64) * VW * 4);
+                ngf[q] = buf_load<VW, AUX_PLAIN>(rg, (lane + q * 64) * VW * 4);
+            }
+            n_fb  = buf_load_f32(make_rsrc(p.fbias + n_bu, 4), 0, false);
+            n_gfb = buf_load_f32(make_rsrc(p.gsfb + n_bu, 4), 0, false);
+        };
+        auto request_context = [&]() {
+            const bool hot = n_key < 0;
+            const int32_t bv = hot ? ~n_key : n_key;
+            rsN_c = make_rsrc(p.context + (int64_t)bv * D, row_bytes);
+            rsN_gc = make_rsrc(p.gsc + (int64_t)bv * D, row_bytes);
+            if (hot) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    cN[q]  = buf_load<VW, AUX_SC1>(rsN_c, (lane + q * 64) * VW * 4);
+                    gcN[q] = buf_load<VW, AUX_SC1>(rsN_gc, (lane + q * 64) * VW * 4);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    cN[q]  = buf_load<VW, AUX_PLAIN>(rsN_c, (lane + q * 64) * VW * 4);
+                    gcN[q] = buf_load<VW, AUX_PLAIN>(rsN_gc, (lane + q * 64) * VW * 4);
+                }
+            }
+            cbN  = buf_load_f32(rs_cb, bv * 4, hot);
+            gcbN = buf_load_f32(rs_gcb, bv * 4, hot);
+        };
+
+        bool open_new = true;
+        if (n_valid > 0) { decode(0); request_focus(); request_context(); }
+        for (int pos = 0; pos < n_valid; ++pos) {
+            const int32_t bu = n_bu, skey = n_key;
+            const float w = n_w; const double l = n_l;
+            VT f[NCH], gf[NCH];
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) { f[q] = nf[q]; gf[q] = ngf[q]; }
+            const float fb = n_fb, gfb = n_gfb;
+            if (open_new) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) { c[q] = cN[q]; gc[q] = gcN[q]; c0[q] = cN[q]; gc0[q] = gcN[q]; }
+                cb = cbN; gcb = gcbN;
+                cur_key = skey; rs_c = rsN_c; rs_gc = rsN_gc;
+            }
+            const bool last = pos + 1 >= n_valid;
+            bool deferred = false, next_new = false;
+            if (!last) {
+                decode(pos + 1);
+                if (n_bu != bu) request_focus(); else deferred = true;    // same focus row twice in a row: re-read after the store
+                next_new = n_key != skey;
+                if (next_new) request_context();
+            }
+            // dot product
+            float part = 0.0f;
+#pragma unroll
+            for (int q = 0; q < NCH; ++q)
+                if (inr[q]) {
 #pragma unroll
                     for (int t = 0; t < VW; ++t) part = __builtin_fmaf(comp<VW>(f[q], t), comp<VW>(c[q], t), part);
                 }
-            }
-#pragma unroll
-            for (int m = G / 2; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
-
+            part = wave_sum(part);
             const float ic = (float)((double)part + ((double)(fb + cb) - l));
             const float wc = w * ic;
-            if (gl == 0) cost_acc += (0.5 * (double)wc) * (double)ic;
+            cost_acc += (0.5 * (double)wc) * (double)ic;
             const float wlr = wc * lr;
+            const __amdgpu_buffer_rsrc_t rf = make_rsrc(p.focus + (int64_t)bu * D, row_bytes);
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.gsf + (int64_t)bu * D, row_bytes);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
-                const int off = (gl + q * G) * VW;
-                if (off < D) {
-                    V nf, nc, ngf, ngc;
+                if (inr[q]) {
+                    VT of, ogf;
 #pragma unroll
                     for (int t = 0; t < VW; ++t) {
                         const float fv = comp<VW>(f[q], t), cv = comp<VW>(c[q], t);
                         const float a = comp<VW>(gf[q], t), b = comp<VW>(gc[q], t);
                         const float grad1 = wc * cv, grad2 = wc * fv;
-                        comp<VW>(nf, t)  = __builtin_fmaf(-(wlr * cv), __frsqrt_rn(a), fv);
-                        comp<VW>(nc, t)  = __builtin_fmaf(-(wlr * fv), __frsqrt_rn(b), cv);
-                        comp<VW>(ngf, t) = __builtin_fmaf(grad1, grad1, a);
-                        comp<VW>(ngc, t) = __builtin_fmaf(grad2, grad2, b);
+                        comp<VW>(of, t)   = __builtin_fmaf(-(wlr * cv), __frsqrt_rn(a), fv);
+                        comp<VW>(ogf, t)  = __builtin_fmaf(grad1, grad1, a);
+                        comp<VW>(c[q], t)  = __builtin_fmaf(-(wlr * fv), __frsqrt_rn(b), cv);
+                        comp<VW>(gc[q], t) = __builtin_fmaf(grad2, grad2, b);
                     }
-                    *reinterpret_cast<V *>(foc + off) = nf;
-                    *reinterpret_cast<V *>(ctx + off) = nc;
-                    *reinterpret_cast<V *>(g1s + off) = ngf;
-                    *reinterpret_cast<V *>(g2s + off) = ngc;
+                    buf_store<VW>(of, rf, (lane + q * 64) * VW * 4);
+                    buf_store<VW>(ogf, rg, (lane + q * 64) * VW * 4);
                 }
             }
-            if (gl == 0) {
-                p.fbias[bu] = fb - wc * __frsqrt_rn(gfb);      // no learning rate on the biases (Adagrad.java:88-89)
-                p.cbias[bv] = cb - wc * __frsqrt_rn(gcb);
-                const float w2 = wc * wc;
-                p.gsfb[bu] = gfb + w2;
-                p.gscb[bv] = gcb + w2;
+            const float w2 = wc * wc;
+            if (lane == 0) {          // no learning rate on the biases (Adagrad.java:88-89)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, fb - wc * __frsqrt_rn(gfb)), make_rsrc(p.fbias + bu, 4), 0, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gfb + w2), make_rsrc(p.gsfb + bu, 4), 0, 0, 0);
             }
+            cb = cb - wc * __frsqrt_rn(gcb);
+            gcb = gcb + w2;
+            if (last || next_new) close_run();
+            if (deferred) request_focus();
+            open_new = next_new;
         }
-        __syncthreads();
     }
-
-    // block-reduce the cost, one fp64 atomic per block
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) cost_acc += __shfl_xor(cost_acc, m, 64);
-    if ((tid & 63) == 0) s_cost[tid >> 6] = cost_acc;
-    __syncthreads();
-    if (tid == 0) {
-        double t = 0.0;
-        for (int q = 0; q < 256 / 64; ++q) t += s_cost[q];
-        if (t != 0.0) atomicAdd(p.cost_out, t);
-    }
+    if (lane == 0 && cost_acc != 0.0) atomicAdd(p.cost_out, cost_acc);
 }
 
-using hogwild_fn = void (*)(GloveParams, int64_t, int64_t);
+using hogwild_fn = void (*)(GloveParams, int64_t, int64_t, int32_t, int32_t);
 
-template <int G, int VW>
+template <int VW>
 hogwild_fn pick_nch(int nch) {
     switch (nch) {
-        case 1: return k_adagrad_hogwild<G, VW, 1>;
-        case 2: return k_adagrad_hogwild<G, VW, 2>;
-        case 3: return k_adagrad_hogwild<G, VW, 3>;
-        case 4: return k_adagrad_hogwild<G, VW, 4>;
-        case 5: return k_adagrad_hogwild<G, VW, 5>;
-        case 6: return k_adagrad_hogwild<G, VW, 6>;
-        case 7: return k_adagrad_hogwild<G, VW, 7>;
-        case 8: return k_adagrad_hogwild<G, VW, 8>;
+        case 1: return k_adagrad_runs<VW, 1>;
+        case 2: return k_adagrad_runs<VW, 2>;
+        case 3: return k_adagrad_runs<VW, 3>;
+        case 4: return k_adagrad_runs<VW, 4>;
         default: return nullptr;
     }
 }
-template <int G>
-hogwild_fn pick_vw(int vw, int nch) {
-    switch (vw) {
-        case 4: return pick_nch<G, 4>(nch);
-        case 2: return pick_nch<G, 2>(nch);
-        default: return pick_nch<G, 1>(nch);
-    }
-}
-// Chooses the lane-group width G and the chunks per lane for a given D.
-hogwild_fn pick_hogwild(int D, int forced_g, int *g_out, int *vw_out, int *nch_out) {
+// One wavefront spans a row: 64 lanes x VW floats x NCH chunks >= D.
+hogwild_fn pick_hogwild(int D, int *vw_out, int *nch_out) {
     const int vw = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
-    const int chunks = (D + vw - 1) / vw;
-    int cand[3] = {16, 32, 64};
-    for (int ci = 0; ci < 3; ++ci) {
-        const int g = cand[ci];
-        if (forced_g && g != forced_g) continue;
-        const int nch = (chunks + g - 1) / g;
-        if (nch > 8) continue;
-        hogwild_fn fn = g == 16 ? pick_vw<16>(vw, nch) : g == 32 ? pick_vw<32>(vw, nch) : pick_vw<64>(vw, nch);
-        if (fn) { *g_out = g; *vw_out = vw; *nch_out = nch; return fn; }
-    }
-    return nullptr;
+    const int nch = (D + 64 * vw - 1) / (64 * vw);
+    hogwild_fn fn = vw == 4 ? pick_nch<4>(nch) : vw == 2 ? pick_nch<2>(nch) : pick_nch<1>(nch);
+    *vw_out = vw; *nch_out = nch;
+    return fn;
 }
 
 }  // namespace
@@ -343,7 +546,9 @@ struct ge_glove {
     int64_t tab_count[GE_STATE_COUNT] = {};
     int32_t *dI = nullptr, *dJ = nullptr, *dperm = nullptr;
     float *dX = nullptr;
-    double *dcost = nullptr;          // Hogwild accumulator
+    double *dL = nullptr;             // Hogwild: log term per nonzero
+    float *dW = nullptr;              // Hogwild: weight per nonzero
+    double *dcost = nullptr;          // Hogwild accumulator (+ the chunk queue word behind it)
     float *djob = nullptr;            // deterministic: per-job fp32 costs
     std::vector<int32_t> perm;        // host copy, GE_SHUFFLE_JAVA
     ge::JavaRandom rng{0};
@@ -353,8 +558,12 @@ struct ge_glove {
     int32_t last_launches = 0;
     int num_cus = 256;
     hogwild_fn hw_fn = nullptr;
-    int hw_g = 0, hw_vw = 0, hw_nch = 0;
-    int hw_blocks_per_cu = 8;
+    int hw_vw = 0, hw_nch = 0;
+    int hw_blocks_per_cu = 4;
+    int hw_blocks = 0;
+    int hw_workers = 0;
+    int32_t hot_cols = 0;
+    int64_t hot_nnz = 0, hot_threshold = 0;
 };
 
 namespace {
@@ -375,8 +584,9 @@ void fill_params(const ge_glove *h, GloveParams &p, int32_t iteration) {
     const int64_t off = h->cfg.row_begin;
     p.focus -= off * h->cfg.dim;  p.gsf -= off * h->cfg.dim;
     p.fbias -= off;               p.gsfb -= off;
-    p.I = h->dI; p.J = h->dJ; p.X = h->dX; p.perm = h->dperm;
+    p.I = h->dI; p.J = h->dJ; p.X = h->dX; p.perm = h->dperm; p.L = h->dL; p.W = h->dW;
     p.cost_out = h->dcost;
+    p.queue = reinterpret_cast<unsigned long long *>(h->dcost + 1);
     p.xmax = h->cfg.xmax; p.N = h->cfg.nnz; p.D = h->cfg.dim;
     p.cost_kind = h->cfg.cost; p.lr = h->cfg.learning_rate;
     p.order_mode = h->cfg.shuffle == GE_SHUFFLE_JAVA ? ORDER_PERM
@@ -428,6 +638,8 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     if (cfg->threads < 1) return ge::fail(GE_ERR_ARG, "threads must be >= 1");
     if (cfg->mode != GE_MODE_HOGWILD && cfg->mode != GE_MODE_DETERMINISTIC) return ge::fail(GE_ERR_ARG, "invalid mode %d", cfg->mode);
     if (cfg->shuffle < GE_SHUFFLE_JAVA || cfg->shuffle > GE_SHUFFLE_NONE) return ge::fail(GE_ERR_ARG, "invalid shuffle %d", cfg->shuffle);
+    if (cfg->workers < 0) return ge::fail(GE_ERR_ARG, "workers must be >= 0");
+    if (cfg->hot_columns < GE_HOT_AUTO || cfg->hot_columns > GE_HOT_ALL) return ge::fail(GE_ERR_ARG, "invalid hot_columns %d", cfg->hot_columns);
     int32_t rb = cfg->row_begin, re = cfg->row_end;
     if (rb == 0 && re == 0) re = cfg->vocab_size;
     if (rb < 0 || re > cfg->vocab_size || rb >= re) return ge::fail(GE_ERR_ARG, "invalid row range [%d,%d)", rb, re);
@@ -463,12 +675,57 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     GE_TRY(hipMalloc((void **)&h->dI, sizeof(int32_t) * nn));
     GE_TRY(hipMalloc((void **)&h->dJ, sizeof(int32_t) * nn));
     GE_TRY(hipMalloc((void **)&h->dX, sizeof(float) * nn));
-    GE_TRY(hipMalloc((void **)&h->dcost, sizeof(double)));
+    GE_TRY(hipMalloc((void **)&h->dcost, 2 * sizeof(double)));
     GE_TRY(hipMalloc((void **)&h->djob, sizeof(float) * (size_t)cfg->threads));
+    std::vector<int32_t> jmarked;     // J with hot columns complemented (kept alive until the copy is done)
+    if (cfg->mode == GE_MODE_HOGWILD) {
+        if (const char *e = std::getenv("GE_GLOVE_BLOCKS_PER_CU")) h->hw_blocks_per_cu = std::max(1, std::atoi(e));
+        h->hw_fn = pick_hogwild(D, &h->hw_vw, &h->hw_nch);
+        if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 1024 for dim%%4==0, 256 for odd dim)", D); }
+        // One wavefront = one sequential worker.  Never more workers than N/1024: a small matrix must
+        // not degenerate into one giant stale batch (the JVM has at most #cores updates in flight).
+        const int groups_per_block = 4;
+        const int64_t chunks = (N + RUN_CHUNK - 1) / RUN_CHUNK;
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(h->hw_fn), 256, 0) == hipSuccess && occ > 0)
+            h->hw_blocks_per_cu = std::getenv("GE_GLOVE_BLOCKS_PER_CU") ? h->hw_blocks_per_cu : occ;   // every worker resident: one wave of blocks
+        int64_t blocks = std::min<int64_t>((chunks + 3) / 4, (int64_t)h->num_cus * h->hw_blocks_per_cu);
+        blocks = std::min<int64_t>(blocks, std::max<int64_t>(1, N / 1024 / groups_per_block));
+        h->hw_blocks = (int)std::max<int64_t>(blocks, 1);
+        h->hw_workers = h->hw_blocks * 4;
+        if (cfg->workers > 0) {                       // explicit worker count (tests, reproducibility)
+            h->hw_workers = (int)std::min<int64_t>(cfg->workers, (int64_t)h->num_cus * 32);
+            h->hw_blocks = (h->hw_workers + 3) / 4;
+        }
+        if (N > 0 && cfg->hot_columns != GE_HOT_NONE) {
+            double theta = 0.25;
+            if (const char *e = std::getenv("GE_GLOVE_HOT_THETA")) theta = std::atof(e);
+            const int64_t inflight = h->hw_workers;
+            int64_t thr = cfg->hot_columns == GE_HOT_ALL ? 0
+                        : std::max<int64_t>(2, (int64_t)std::ceil(theta * (double)N / (double)inflight));
+            std::vector<int32_t> cnt((size_t)V, 0);
+            for (int64_t k = 0; k < N; ++k) ++cnt[(size_t)J[k]];
+            jmarked.assign(J, J + N);
+            for (int64_t k = 0; k < N; ++k)
+                if (cnt[(size_t)J[k]] >= thr) { jmarked[(size_t)k] = ~J[k]; ++h->hot_nnz; }
+            for (int32_t v = 0; v < V; ++v) if (cnt[(size_t)v] >= thr && cnt[(size_t)v] > 0) ++h->hot_cols;
+            h->hot_threshold = thr;
+        }
+    } else if ((size_t)D * sizeof(float) > 64 * 1024) {
+        ge_glove_destroy(h);
+        return ge::fail(GE_ERR_ARG, "dim %d too large for deterministic mode", D);
+    }
     if (N > 0) {
         GE_TRY(hipMemcpyAsync(h->dI, I, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
-        GE_TRY(hipMemcpyAsync(h->dJ, J, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+        GE_TRY(hipMemcpyAsync(h->dJ, jmarked.empty() ? J : jmarked.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
         GE_TRY(hipMemcpyAsync(h->dX, X, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+        if (cfg->mode == GE_MODE_HOGWILD) {
+            GE_TRY(hipMalloc((void **)&h->dL, sizeof(double) * nn));
+            GE_TRY(hipMalloc((void **)&h->dW, sizeof(float) * nn));
+            const int blocks = (int)std::min<int64_t>((N + 255) / 256, 8192);
+            hipLaunchKernelGGL(k_cost_terms, dim3(blocks), dim3(256), 0, h->stream, h->dX, N, cfg->cost, cfg->xmax, h->dL, h->dW);
+        }
+        GE_TRY(hipStreamSynchronize(h->stream));
     }
     if (cfg->shuffle == GE_SHUFFLE_JAVA) {
         GE_TRY(hipMalloc((void **)&h->dperm, sizeof(int32_t) * nn));
@@ -511,16 +768,6 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     GE_TRY(hipStreamSynchronize(h->stream));
     h->rng.s = ge::JavaRandom::jump(s0, (uint64_t)V * (uint64_t)(2 + 2 * D));
 
-    if (cfg->mode == GE_MODE_HOGWILD) {
-        int forced = 0;
-        if (const char *e = std::getenv("GE_GLOVE_GROUP")) forced = std::atoi(e);
-        if (const char *e = std::getenv("GE_GLOVE_BLOCKS_PER_CU")) h->hw_blocks_per_cu = std::max(1, std::atoi(e));
-        h->hw_fn = pick_hogwild(D, forced, &h->hw_g, &h->hw_vw, &h->hw_nch);
-        if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 2048 for dim%%4==0)", D); }
-    } else if ((size_t)D * sizeof(float) > 64 * 1024) {
-        ge_glove_destroy(h);
-        return ge::fail(GE_ERR_ARG, "dim %d too large for deterministic mode", D);
-    }
 #undef GE_TRY
     *out = h;
     return GE_OK;
@@ -564,12 +811,10 @@ ge_status ge_glove_epoch(ge_glove *h, int32_t iteration, double *cost_sum) {
         GE_HIP(hipStreamSynchronize(h->stream));
         for (int t = 0; t < T; ++t) total += (double)jc[(size_t)t];       // localCost += job result (Optimizer.java:89)
     } else {
-        GE_HIP(hipMemsetAsync(h->dcost, 0, sizeof(double), h->stream));
+        GE_HIP(hipMemsetAsync(h->dcost, 0, 2 * sizeof(double), h->stream));
         GE_HIP(hipEventRecord(h->ev0, h->stream));
         if (N > 0) {
-            const int64_t tiles = (N + HW_TILE - 1) / HW_TILE;
-            const int blocks = (int)std::min<int64_t>(tiles, (int64_t)h->num_cus * h->hw_blocks_per_cu);
-            hipLaunchKernelGGL(h->hw_fn, dim3(blocks), dim3(256), 0, h->stream, p, (int64_t)0, N);
+            hipLaunchKernelGGL(h->hw_fn, dim3(h->hw_blocks), dim3(256), 0, h->stream, p, (int64_t)0, N, h->cfg.vocab_size, (int32_t)h->hw_workers);
             ++h->last_launches;
         }
         GE_HIP(hipEventRecord(h->ev1, h->stream));
@@ -654,6 +899,16 @@ ge_status ge_glove_last_kernel_ms(ge_glove *h, float *ms, int32_t *launches) {
     return GE_OK;
 }
 
+ge_status ge_glove_get_info(ge_glove *h, ge_glove_info *info) {
+    if (!h || !info) return ge::fail(GE_ERR_ARG, "null argument");
+    std::memset(info, 0, sizeof(*info));
+    info->group_width = 64; info->vector_width = h->hw_vw; info->chunks_per_lane = h->hw_nch;
+    info->blocks = h->cfg.mode == GE_MODE_HOGWILD ? h->hw_blocks : 1;
+    info->groups_in_flight = h->cfg.mode == GE_MODE_HOGWILD ? h->hw_workers : 1;
+    info->hot_columns = h->hot_cols; info->hot_nonzeros = h->hot_nnz; info->hot_threshold = h->hot_threshold;
+    return GE_OK;
+}
+
 void ge_glove_destroy(ge_glove *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
@@ -662,6 +917,8 @@ void ge_glove_destroy(ge_glove *h) {
     if (h->dJ) (void)hipFree(h->dJ);
     if (h->dX) (void)hipFree(h->dX);
     if (h->dperm) (void)hipFree(h->dperm);
+    if (h->dL) (void)hipFree(h->dL);
+    if (h->dW) (void)hipFree(h->dW);
     if (h->dcost) (void)hipFree(h->dcost);
     if (h->djob) (void)hipFree(h->djob);
     if (h->ev0) (void)hipEventDestroy(h->ev0);

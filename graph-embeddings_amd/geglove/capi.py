@@ -16,6 +16,7 @@ GE_OPT_ADAGRAD = 0
 GE_NORM_NONE, GE_NORM_UNITY, GE_NORM_COUNTS = 0, 1, 2
 GE_MODE_HOGWILD, GE_MODE_DETERMINISTIC = 0, 1
 GE_SHUFFLE_JAVA, GE_SHUFFLE_DEVICE, GE_SHUFFLE_NONE = 0, 1, 2
+GE_HOT_AUTO, GE_HOT_NONE, GE_HOT_ALL = 0, 1, 2
 (GE_STATE_FOCUS, GE_STATE_CONTEXT, GE_STATE_FBIAS, GE_STATE_CBIAS, GE_STATE_GSQ_FOCUS,
  GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FBIAS, GE_STATE_GSQ_CBIAS) = range(8)
 STATE_NAMES = ("focus", "context", "fbias", "cbias", "gsq_focus", "gsq_context", "gsq_fbias", "gsq_cbias")
@@ -24,7 +25,7 @@ STATE_NAMES = ("focus", "context", "fbias", "cbias", "gsq_focus", "gsq_context",
 SYMBOLS = (
     "ge_glove_cfg_default", "ge_glove_create", "ge_glove_epoch", "ge_glove_extract_f32",
     "ge_glove_extract_f64", "ge_glove_get_state", "ge_glove_set_state", "ge_glove_device_ptr",
-    "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_destroy",
+    "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
     "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_last_error", "ge_version", "ge_device_count",
 )
 
@@ -34,7 +35,14 @@ class GloveCfg(C.Structure):
                 ("cost", C.c_int32), ("opt", C.c_int32), ("learning_rate", C.c_float),
                 ("xmax", C.c_double), ("seed", C.c_int64), ("threads", C.c_int32),
                 ("mode", C.c_int32), ("shuffle", C.c_int32), ("device", C.c_int32),
-                ("stream", C.c_void_p), ("row_begin", C.c_int32), ("row_end", C.c_int32)]
+                ("stream", C.c_void_p), ("row_begin", C.c_int32), ("row_end", C.c_int32),
+                ("hot_columns", C.c_int32), ("workers", C.c_int32)]
+
+
+class GloveInfo(C.Structure):
+    _fields_ = [("group_width", C.c_int32), ("vector_width", C.c_int32), ("chunks_per_lane", C.c_int32),
+                ("blocks", C.c_int32), ("groups_in_flight", C.c_int32), ("hot_columns", C.c_int32),
+                ("hot_nonzeros", C.c_int64), ("hot_threshold", C.c_int64)]
 
 
 class Csr(C.Structure):
@@ -79,6 +87,7 @@ def lib():
     L.ge_glove_get_perm.argtypes = [vp, i32p, C.c_int64]
     L.ge_glove_rng_state.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ge_glove_last_kernel_ms.argtypes = [vp, f32p, i32p]
+    L.ge_glove_get_info.argtypes = [vp, C.POINTER(GloveInfo)]
     L.ge_glove_destroy.argtypes = [vp]; L.ge_glove_destroy.restype = None
     L.ge_bca_build.argtypes = [C.POINTER(Csr), C.POINTER(Csr), C.POINTER(BcaCfg), C.POINTER(vp)]
     L.ge_coo_get.argtypes = [vp, i64p, C.POINTER(i32p), C.POINTER(i32p), C.POINTER(f32p), C.POINTER(i64p), f64p]

@@ -189,6 +189,7 @@ class Optimum:
 
 
 _MODES = {"hogwild": capi.GE_MODE_HOGWILD, "deterministic": capi.GE_MODE_DETERMINISTIC}
+_HOT = {"auto": capi.GE_HOT_AUTO, "none": capi.GE_HOT_NONE, "all": capi.GE_HOT_ALL}
 _SHUFFLES = {"java": capi.GE_SHUFFLE_JAVA, "device": capi.GE_SHUFFLE_DEVICE, "none": capi.GE_SHUFFLE_NONE}
 
 
@@ -225,6 +226,8 @@ class Adagrad:
         cfg.stream = dev.get("stream", None)
         rb, re = dev.get("row_range", (0, 0))
         cfg.row_begin, cfg.row_end = rb, re
+        cfg.hot_columns = _HOT[str(dev.get("hot", "auto")).lower()]
+        cfg.workers = int(dev.get("workers", 0))
         self._rows = (re - rb) if (rb, re) != (0, 0) else self.vocabSize
         self._cfg = cfg
         self._h = C.c_void_p()
@@ -322,6 +325,11 @@ class Adagrad:
         ms = C.c_float(); n = C.c_int32()
         capi.check(capi.lib().ge_glove_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def info(self):
+        inf = capi.GloveInfo()
+        capi.check(capi.lib().ge_glove_get_info(self._h, C.byref(inf)))
+        return {k: getattr(inf, k) for k, _ in capi.GloveInfo._fields_}
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

@@ -62,6 +62,15 @@ enum { GE_MODE_HOGWILD = 0, GE_MODE_DETERMINISTIC = 1 };
  * NONE:   matrix order (no shuffle). */
 enum { GE_SHUFFLE_JAVA = 0, GE_SHUFFLE_DEVICE = 1, GE_SHUFFLE_NONE = 2 };
 
+/* Lock-free does not mean lossy on a GPU: ~10^4 lane groups are in flight (the JVM has <= #cores
+ * threads), so a hub column j that appears in a large share of the nonzeros would lose most of its
+ * concurrent plain read-modify-write updates.  Nonzeros of such "hot" columns therefore update the
+ * context side with float atomic adds (no update is lost; gradients may be a few microseconds
+ * stale, as under Hogwild) and read it with agent-coherent loads.
+ * AUTO: column j is hot when  count(j) * groups_in_flight >= 0.25 * N  (library default).
+ * NONE: plain stores everywhere (the literal Java race).  ALL: every column (tests). */
+enum { GE_HOT_AUTO = 0, GE_HOT_NONE = 1, GE_HOT_ALL = 2 };
+
 /* Parameter tables a caller can read or write (tests, checkpointing, multi-GPU sync). */
 enum {
     GE_STATE_FOCUS = 0,        /* float[V*D]  Optimizer.focus         (J/opt/Optimizer.java:27) */
@@ -98,7 +107,24 @@ typedef struct {
     void   *stream;         /* hipStream_t to launch on, or NULL for the device's null stream          */
     int32_t row_begin;      /* multi-GPU row sharding: this handle owns focus rows      */
     int32_t row_end;        /*   [row_begin,row_end); 0,0 = all rows.  I[] must lie inside the range.  */
+    int32_t hot_columns;    /* GE_HOT_* (HOGWILD mode only)                                            */
+    int32_t workers;        /* HOGWILD: number of sequential workers (wavefronts); 0 = fill the device.
+                               Workers pull chunks of 128 consecutive nonzeros of the epoch order from a queue
+                               and walk each chunk in stable column order; workers = 1 is fully sequential. */
 } ge_glove_cfg;
+
+/* What the library decided for a handle (reporting / DESIGN.md numbers). */
+typedef struct {
+    int32_t group_width;      /* lanes that own one nonzero (16, 32 or 64)                 */
+    int32_t vector_width;     /* floats per lane access (4, 2 or 1)                        */
+    int32_t chunks_per_lane;
+    int32_t blocks;           /* workgroups launched per epoch                             */
+    int32_t groups_in_flight; /* sequential workers (wavefronts) in flight                 */
+    int32_t hot_columns;      /* columns updated with atomics                              */
+    int64_t hot_nonzeros;     /* nonzeros whose column is hot                              */
+    int64_t hot_threshold;    /* count(j) >= this => hot                                   */
+} ge_glove_info;
+
 
 /* Fills *cfg with the reference's defaults (adagrad, lr 0.05f, threads 1, HOGWILD, DEVICE shuffle). */
 void ge_glove_cfg_default(ge_glove_cfg *cfg);
@@ -136,6 +162,8 @@ ge_status ge_glove_rng_state(ge_glove *h, uint64_t *state);
 /* Device time of the last epoch's update kernel(s), measured with hipEvents on the launch
  * stream, in milliseconds; *launches = number of kernel launches it covered. */
 ge_status ge_glove_last_kernel_ms(ge_glove *h, float *ms, int32_t *launches);
+
+ge_status ge_glove_get_info(ge_glove *h, ge_glove_info *info);
 
 void ge_glove_destroy(ge_glove *h);
 

@@ -29,4 +29,7 @@ def assert_state_equal(dev_state, ora, exact=True, rtol=0.0, atol=0.0, what=""):
             assert bad.size == 0, "%s %s: %d of %d words differ, first at %d: %r vs %r" % (
                 what, name, bad.size, a.size, bad[0], a[bad[0]], b[bad[0]])
         else:
-            np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, err_msg="%s %s" % (what, name))
+            # atol is relative to the table's largest magnitude (elements near zero carry the
+            # absolute rounding error of the update, not a relative one)
+            scale = float(np.max(np.abs(b))) if b.size else 1.0
+            np.testing.assert_allclose(a, b, rtol=rtol, atol=atol * scale, err_msg="%s %s" % (what, name))
