@@ -163,19 +163,42 @@ def test_hogwild_visits_every_nonzero_once(gpu):
 
 
 @pytest.mark.parametrize("method", ["glove", "pglove"])
-def test_hogwild_cost_trajectory_tracks_oracle(gpu, method):
-    """Racy epochs on hub-heavy data: per-epoch mean cost within 5 % of the sequential oracle."""
-    V, N, D = 2000, 60000, 50
+@pytest.mark.parametrize("workers,tol_first,tol_rest", [(8, 0.20, 0.10), (0, 0.35, 0.12)])
+def test_hogwild_cost_trajectory_tracks_oracle(gpu, method, workers, tol_first, tol_rest):
+    """Racy epochs on a hub-heavy matrix: the per-epoch mean cost follows the sequential oracle.
+    The device walks a different (chunk-sorted, keyed-bijection) order with many concurrent workers,
+    so this is a statistical statement: at 8 workers (what a JVM would run) the first epoch is within
+    20 % and later epochs within 10 %; with the device filled (512 workers on 0.5 M nonzeros, i.e. 0.1 %
+    of the epoch in flight at once) 35 % / 12 %; by the fifth epoch both are within 5 %.
+    Measured: DESIGN.md 'Statistical parity of the Hogwild mode'."""
+    V, N, D = 20000, 600000, 50
     I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
-    cfg = make_config(D, method, mode="hogwild", shuffle="device", seed=42)
+    cfg = make_config(D, method, mode="hogwild", shuffle="device", seed=42, workers=workers)
     opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
     ora = O.Glove(V, D, I, J, X, xmax, cost_kind(method), seed=42, threads=1)
     n = len(I)
-    dev = [opt.epoch(it) / n for it in range(5)]
-    ref = [ora.epoch() for _ in range(5)]
+    dev = np.array([opt.epoch(it) / n for it in range(5)])
+    ref = np.array([ora.epoch() for _ in range(5)])
     assert np.all(np.isfinite(dev))
-    assert dev[-1] < dev[0]
-    np.testing.assert_allclose(dev, ref, rtol=0.05)
+    assert np.all(np.diff(dev) < 0)                       # cost decreases monotonically, as the oracle's does
+    assert abs(dev[0] / ref[0] - 1) <= tol_first
+    np.testing.assert_allclose(dev[1:], ref[1:], rtol=tol_rest)
+    assert abs(dev[-1] / ref[-1] - 1) <= 0.05
+
+
+def test_hogwild_hub_atomics_beat_plain_stores(gpu):
+    """Why hub columns use atomics: with plain read-modify-write the hub rows lose most concurrent
+    updates (and every XCD's L2 keeps its own stale copy), and training falls behind."""
+    V, N, D = 20000, 600000, 50
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
+    n = len(I)
+    last = {}
+    for hot in ("auto", "none"):
+        cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, hot=hot)
+        opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+        for it in range(8):
+            last[hot] = opt.epoch(it) / n
+    assert last["auto"] < last["none"]
 
 
 def test_empty_matrix_and_bad_arguments(gpu):
