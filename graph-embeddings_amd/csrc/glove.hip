@@ -682,7 +682,7 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
         if (const char *e = std::getenv("GE_GLOVE_BLOCKS_PER_CU")) h->hw_blocks_per_cu = std::max(1, std::atoi(e));
         h->hw_fn = pick_hogwild(D, &h->hw_vw, &h->hw_nch);
         if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 1024 for dim%%4==0, 256 for odd dim)", D); }
-        // One wavefront = one sequential worker.  Never more workers than N/1024: a small matrix must
+        // One wavefront = one sequential worker.  Never more workers than N/2048: a small matrix must
         // not degenerate into one giant stale batch (the JVM has at most #cores updates in flight).
         const int groups_per_block = 4;
         const int64_t chunks = (N + RUN_CHUNK - 1) / RUN_CHUNK;
@@ -690,7 +690,7 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(h->hw_fn), 256, 0) == hipSuccess && occ > 0)
             h->hw_blocks_per_cu = std::getenv("GE_GLOVE_BLOCKS_PER_CU") ? h->hw_blocks_per_cu : occ;   // every worker resident: one wave of blocks
         int64_t blocks = std::min<int64_t>((chunks + 3) / 4, (int64_t)h->num_cus * h->hw_blocks_per_cu);
-        blocks = std::min<int64_t>(blocks, std::max<int64_t>(1, N / 1024 / groups_per_block));
+        blocks = std::min<int64_t>(blocks, std::max<int64_t>(1, N / 2048 / groups_per_block));
         h->hw_blocks = (int)std::max<int64_t>(blocks, 1);
         h->hw_workers = h->hw_blocks * 4;
         if (cfg->workers > 0) {                       // explicit worker count (tests, reproducibility)
