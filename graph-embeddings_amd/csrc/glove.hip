@@ -225,9 +225,9 @@ __device__ __forceinline__ typename Vec<VW>::T buf_load(__amdgpu_buffer_rsrc_t r
 }
 template <int VW>
 __device__ __forceinline__ void buf_store(typename Vec<VW>::T val, __amdgpu_buffer_rsrc_t rs, int off) {
-    if constexpr (VW == 4) { ge_i4 v; __builtin_memcpy(&v, &val, 16); __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0); }
-    else if constexpr (VW == 2) { ge_i2 v; __builtin_memcpy(&v, &val, 8); __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, 0); }
-    else { int v; __builtin_memcpy(&v, &val, 4); __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0); }
+    if constexpr (VW == 4) { ge_i4 v; __builtin_memcpy(&v, &val, 16); __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, AUX_SC1); }
+    else if constexpr (VW == 2) { ge_i2 v; __builtin_memcpy(&v, &val, 8); __builtin_amdgcn_raw_buffer_store_b64(v, rs, off, 0, AUX_SC1); }
+    else { int v; __builtin_memcpy(&v, &val, 4); __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, AUX_SC1); }
 }
 __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t rs, int off, bool coherent) {
     int v = coherent ? __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, AUX_SC1)
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
                     buf_store<VW>(gc[q], rs_gc, (lane + q * 64) * VW * 4);
                 }
                 if (lane == 0) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cb), rs_cb, bv * 4, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gcb), rs_gcb, bv * 4, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cb), rs_cb, bv * 4, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gcb), rs_gcb, bv * 4, 0, AUX_SC1);
                 }
             } else {
                 // Publish the run's delta with float atomics.  Lane L holds elements [VW*L, VW*L+VW);
@@ -414,11 +414,11 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
             const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.gsf + (int64_t)n_bu * D, row_bytes);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
-                nf[q]  = buf_load<VW, AUX_PLAIN>(rf, (lane + q * 64) * VW * 4);
-                ngf[q] = buf_load<VW, AUX_PLAIN>(rg, (lane + q * 64) * VW * 4);
+                nf[q]  = buf_load<VW, AUX_SC1>(rf, (lane + q * 64) * VW * 4);
+                ngf[q] = buf_load<VW, AUX_SC1>(rg, (lane + q * 64) * VW * 4);
             }
-            n_fb  = buf_load_f32(make_rsrc(p.fbias + n_bu, 4), 0, false);
-            n_gfb = buf_load_f32(make_rsrc(p.gsfb + n_bu, 4), 0, false);
+            n_fb  = buf_load_f32(make_rsrc(p.fbias + n_bu, 4), 0, true);
+            n_gfb = buf_load_f32(make_rsrc(p.gsfb + n_bu, 4), 0, true);
         };
         auto request_context = [&]() {
             const bool hot = n_key < 0;
@@ -434,12 +434,12 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
             } else {
 #pragma unroll
                 for (int q = 0; q < NCH; ++q) {
-                    cN[q]  = buf_load<VW, AUX_PLAIN>(rsN_c, (lane + q * 64) * VW * 4);
-                    gcN[q] = buf_load<VW, AUX_PLAIN>(rsN_gc, (lane + q * 64) * VW * 4);
+                    cN[q]  = buf_load<VW, AUX_SC1>(rsN_c, (lane + q * 64) * VW * 4);
+                    gcN[q] = buf_load<VW, AUX_SC1>(rsN_gc, (lane + q * 64) * VW * 4);
                 }
             }
-            cbN  = buf_load_f32(rs_cb, bv * 4, hot);
-            gcbN = buf_load_f32(rs_gcb, bv * 4, hot);
+            cbN  = buf_load_f32(rs_cb, bv * 4, true);
+            gcbN = buf_load_f32(rs_gcb, bv * 4, true);
         };
 
         bool open_new = true;
@@ -500,8 +500,8 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
             }
             const float w2 = wc * wc;
             if (lane == 0) {          // no learning rate on the biases (Adagrad.java:88-89)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, fb - wc * __frsqrt_rn(gfb)), make_rsrc(p.fbias + bu, 4), 0, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gfb + w2), make_rsrc(p.gsfb + bu, 4), 0, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, fb - wc * __frsqrt_rn(gfb)), make_rsrc(p.fbias + bu, 4), 0, 0, AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gfb + w2), make_rsrc(p.gsfb + bu, 4), 0, 0, AUX_SC1);
             }
             cb = cb - wc * __frsqrt_rn(gcb);
             gcb = gcb + w2;

@@ -163,14 +163,14 @@ def test_hogwild_visits_every_nonzero_once(gpu):
 
 
 @pytest.mark.parametrize("method", ["glove", "pglove"])
-@pytest.mark.parametrize("workers,tol_first,tol_rest", [(8, 0.20, 0.10), (0, 0.45, 0.25)])
+@pytest.mark.parametrize("workers,tol_first,tol_rest", [(8, 0.08, 0.02), (0, 0.08, 0.02)])
 def test_hogwild_cost_trajectory_tracks_oracle(gpu, method, workers, tol_first, tol_rest):
     """Racy epochs on a hub-heavy matrix: the per-epoch mean cost follows the sequential oracle.
-    The device walks a different (chunk-sorted, keyed-bijection) order with many concurrent workers,
-    so this is a statistical statement: at 8 workers (what a JVM would run) the first epoch is within
-    20 % and later epochs within 10 %; with the device filled (512 workers on 0.5 M nonzeros, i.e. 0.1 %
-    of the epoch in flight at once) 45 % / 25 %; by the fifth epoch they are within 5 % / 10 %.
-    Measured: DESIGN.md 'Statistical parity of the Hogwild mode'."""
+    The device walks a different order (keyed bijection, chunks sorted by column) with many workers
+    at once, so this is a statistical statement: first epoch within 8 %, every later epoch within 2 %,
+    both at 8 workers (what a JVM would run) and with the library's own choice (256 workers on 0.5 M
+    nonzeros).  Measured 1.3 % / 0.6 % (glove) and 3.9 % / 0.2 % (pglove); DESIGN.md has the table.
+    This only holds because every table access is agent-coherent (sc1) and hub columns use atomics."""
     V, N, D = 20000, 600000, 50
     I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
     cfg = make_config(D, method, mode="hogwild", shuffle="device", seed=42, workers=workers)
@@ -183,7 +183,6 @@ def test_hogwild_cost_trajectory_tracks_oracle(gpu, method, workers, tol_first, 
     assert np.all(np.diff(dev) < 0)                       # cost decreases monotonically, as the oracle's does
     assert abs(dev[0] / ref[0] - 1) <= tol_first
     np.testing.assert_allclose(dev[1:], ref[1:], rtol=tol_rest)
-    assert abs(dev[-1] / ref[-1] - 1) <= (0.05 if workers else 0.10)
 
 
 def test_hogwild_hub_atomics_beat_plain_stores(gpu):
