@@ -1,12 +1,637 @@
-// bca.hip -- placeholder until the device builder lands (next milestone).
+// bca.hip -- Bookmark Coloring co-occurrence builder for MI355X (gfx950): kernels + C ABI.
+//
+// Reference semantics (J/ = src/main/java/org/uu/nl/embedding/ of Phaken/graph-embeddings):
+//   BookmarkColoring ctor            J/bca/BookmarkColoring.java:32-120   -> ge_bca_build
+//   DirectedWeighted.doWork          J/bca/jobs/DirectedWeighted.java:31-101
+//   UndirectedWeighted.doWork        J/bca/jobs/UndirectedWeighted.java:31-114   -> bca_pass()
+//   BCAJob.call (fwd + forced reverse, merged)   J/bca/util/BCAJob.java:31-36
+//   BCV add / merge / toUnity / toCounts / max   J/bca/util/BCV.java:35-107
+//
+// One wavefront runs one bookmark at a time (V independent jobs, pulled from a queue).  The paint
+// that is still "wet" lives in a per-wave open-addressing table keyed by node id (fp64, as
+// PaintedNode.paint) plus a compact list of the ids currently in the TreeMap; the next node is the
+// LOWEST id in that list (TreeMap.pollFirstEntry), found with a wave-wide min.  A pop spreads to up
+// to 64 neighbours per step, one neighbour per lane (neighbour lists are unique, so lanes never
+// collide on a node).  All fp64/fp32 operations are the reference's, in the reference's order
+// (-ffp-contract=off), so the values are bit-exact; the row is emitted in java.util.HashMap
+// iteration order (bucket = (k ^ k>>>16) & (cap-1); putVal appends at the bin tail, merge() links
+// new keys at the bin head and resizes before the lookup) -- treeified bins are not emulated,
+// like in the oracle.
+//
+// Roofline: none of HBM/MFMA -- this is latency-bound pointer chasing over a small working set; it
+// runs once per graph, against minutes for the JVM.  Measured in DESIGN.md.
+
 #include "ge_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr int32_t KEY_EMPTY = -1;
+
+struct BcaGraph {
+    const int64_t *out_ptr, *in_ptr;
+    const int32_t *out_idx, *in_idx;
+    const float *out_w, *in_w;
+    const double *tot_out, *tot_in, *tot_und;
+    int32_t V;
+};
+
+struct BcaWork {           // per-wave workspace (struct of arrays, `hc` slots each)
+    int32_t *hkey;         // node id or KEY_EMPTY
+    int32_t *hin;          // 1 while the node is in the TreeMap
+    double  *hpaint;       // PaintedNode.paint
+    float   *fval, *rval;  // BCV value of the forward / reverse pass
+    int32_t *fseq, *rseq;  // BCV insertion sequence (-1 = not in that BCV)
+    int32_t *touched;      // slots in use (hc/2)
+    int32_t *alist;        // ids currently in the TreeMap (ac)
+    unsigned long long *okey;   // sort keys (hc/2)
+    int32_t *oslot;        // slot per row entry (hc/2)
+    int32_t *rpos;         // reverse-BCV iteration position -> slot (hc/2)
+    int32_t *rnew;         // reverse-BCV iteration position -> 1 if the key is new to the forward BCV
+};
+
+struct BcaParams {
+    BcaGraph g;
+    double alpha, epsilon;
+    int32_t directed, normalize;
+    int32_t row_begin, row_end;
+    int32_t hc, hc_log2, ac;           // table slots (power of two), active-list capacity
+    char *work;                        // n_waves * work_stride bytes
+    int64_t work_stride;
+    // outputs
+    int32_t *row_n;                    // per bookmark (relative to row_begin)
+    int64_t *row_off;
+    float *row_max;                    // bcv.max() after normalisation
+    int32_t *outJ; float *outX;        // row pool
+    int64_t out_cap;
+    unsigned long long *pool_used;     // bump allocator
+    unsigned long long *queue;         // next bookmark
+    int32_t *status;                   // 0 ok, 1 table overflow, 2 active-list overflow, 3 pool overflow
+};
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    const unsigned lane = threadIdx.x & 63;
+    return lane == 0 ? 0ull : (~0ull >> (64 - lane));
+}
+__device__ __forceinline__ uint32_t java_hash(int32_t k) { const uint32_t h = (uint32_t)k; return h ^ (h >> 16); }
+// capacity a java.util.HashMap reaches after `n` putVal insertions (16, load factor 0.75)
+__device__ __forceinline__ int32_t java_cap_after_puts(int32_t n) { int32_t c = 16; while (n > (c / 4) * 3) c <<= 1; return c; }
+
+__device__ __forceinline__ BcaWork carve(const BcaParams &p, int wave) {
+    char *b = p.work + (int64_t)wave * p.work_stride;
+    BcaWork w;
+    const int64_t hc = p.hc, half = p.hc / 2;
+    w.hpaint = (double *)b;                 b += 8 * hc;
+    w.okey = (unsigned long long *)b;       b += 8 * half;
+    w.hkey = (int32_t *)b;                  b += 4 * hc;
+    w.hin = (int32_t *)b;                   b += 4 * hc;
+    w.fval = (float *)b;                    b += 4 * hc;
+    w.rval = (float *)b;                    b += 4 * hc;
+    w.fseq = (int32_t *)b;                  b += 4 * hc;
+    w.rseq = (int32_t *)b;                  b += 4 * hc;
+    w.touched = (int32_t *)b;               b += 4 * half;
+    w.oslot = (int32_t *)b;                 b += 4 * half;
+    w.rpos = (int32_t *)b;                  b += 4 * half;
+    w.rnew = (int32_t *)b;                  b += 4 * half;
+    w.alist = (int32_t *)b;
+    return w;
+}
+inline int64_t work_bytes(int64_t hc, int64_t ac) { return 8 * hc + 8 * (hc / 2) + 4 * hc * 6 + 4 * (hc / 2) * 4 + 4 * ac; }
+
+// find the slot of `key` (must exist); wave-uniform key
+__device__ __forceinline__ int32_t table_find(const BcaWork &w, const BcaParams &p, int32_t key) {
+    uint32_t slot = ((uint32_t)key * 2654435761u) >> (32 - p.hc_log2);
+    for (;;) {
+        if (__hip_atomic_load(w.hkey + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == key) return (int32_t)slot;
+        slot = (slot + 1) & (uint32_t)(p.hc - 1);
+    }
+}
+
+// One pass = DirectedWeighted.doWork(reverse) or UndirectedWeighted.doWork.
+// mode 0: out-neighbours, 1: in-neighbours, 2: undirected (out then in, one shared total).
+// Returns false on overflow.  n_touched / n_seq are wave-uniform running counters.
+__device__ bool bca_pass(const BcaParams &p, const BcaWork &w, int32_t bookmark, int mode, bool reverse_bcv,
+                         int32_t &n_touched, int32_t &n_seq, int32_t *status) {
+    const int lane = threadIdx.x & 63;
+    const double alpha = p.alpha, epsilon = p.epsilon;
+    float *val = reverse_bcv ? w.rval : w.fval;
+    int32_t *seq = reverse_bcv ? w.rseq : w.fseq;
+    int32_t an = 0;
+
+    // lane-parallel: each active lane adds paint `pt` to node `nb` (TreeMap containsKey/get/put)
+    auto tree_add = [&](bool act, int32_t nb, double pt) -> bool {
+        int32_t slot = 0; bool inserted = false;
+        if (act) {
+            uint32_t s = ((uint32_t)nb * 2654435761u) >> (32 - p.hc_log2);
+            for (int probe = 0;; ++probe) {
+                const int32_t k = __hip_atomic_load(w.hkey + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (k == nb) break;
+                if (k == KEY_EMPTY) {
+                    int32_t expected = KEY_EMPTY;
+                    if (__hip_atomic_compare_exchange_strong(w.hkey + s, &expected, nb, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_WAVEFRONT)) { inserted = true; break; }
+                    if (expected == nb) break;
+                }
+                s = (s + 1) & (uint32_t)(p.hc - 1);
+                if (probe > p.hc) break;
+            }
+            slot = (int32_t)s;
+        }
+        // register new slots
+        const unsigned long long mi = __ballot(inserted);
+        if (inserted) {
+            const int pos = n_touched + __popcll(mi & lanemask_lt());
+            if (pos < p.hc / 2) w.touched[pos] = slot;
+            w.hin[slot] = 0; w.fseq[slot] = -1; w.rseq[slot] = -1;
+        }
+        n_touched += __popcll(mi);
+        if (n_touched > p.hc / 2) { if (lane == 0) *status = 1; return false; }
+        // paint
+        bool fresh = false;
+        if (act) {
+            if (w.hin[slot]) w.hpaint[slot] = w.hpaint[slot] + pt;      // nodeTree.get(n).addPaint(p)
+            else { w.hpaint[slot] = pt; w.hin[slot] = 1; fresh = true; }  // nodeTree.put(n, new PaintedNode(n, p))
+        }
+        const unsigned long long mf = __ballot(fresh);
+        if (fresh) {
+            const int pos = an + __popcll(mf & lanemask_lt());
+            if (pos < p.ac) w.alist[pos] = nb;
+        }
+        an += __popcll(mf);
+        if (an > p.ac) { if (lane == 0) *status = 2; return false; }
+        wave_sync();
+        return true;
+    };
+
+    if (!tree_add(lane == 0, bookmark, 1.0)) return false;           // nodeTree.put(bookmark, PaintedNode(bookmark, 1))
+
+    while (an > 0) {
+        // pollFirstEntry(): lowest node id
+        unsigned long long best = ~0ull;
+        for (int i = lane; i < an; i += 64) {
+            const unsigned long long c = ((unsigned long long)(uint32_t)w.alist[i] << 32) | (uint32_t)i;
+            best = c < best ? c : best;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(best, m, 64); best = o < best ? o : best; }
+        const int32_t focus = rfl((int)(best >> 32));
+        const int32_t fpos = rfl((int)(best & 0xFFFFFFFFull));
+        if (lane == 0) w.alist[fpos] = w.alist[an - 1];
+        --an;
+        const int32_t fslot = table_find(w, p, focus);
+        const double wet = w.hpaint[fslot];
+        const int32_t old_seq = seq[fslot];
+        wave_sync();
+        if (lane == 0) {
+            w.hin[fslot] = 0;
+            // bcv.add(focus, (float)(alpha * wet)): put(key, getOrDefault(key, 0f) + value)
+            const float add = (float)(alpha * wet);
+            if (old_seq < 0) { seq[fslot] = n_seq; val[fslot] = 0.0f + add; }
+            else val[fslot] = val[fslot] + add;
+        }
+        if (old_seq < 0) ++n_seq;
+        wave_sync();
+        if (wet < epsilon) continue;
+
+        double total;
+        int64_t ob = 0, oe = 0, ib = 0, ie = 0;
+        if (mode == 0) { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; total = p.g.tot_out[focus]; }
+        else if (mode == 1) { ob = p.g.in_ptr[focus]; oe = p.g.in_ptr[focus + 1]; total = p.g.tot_in[focus]; }
+        else { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; ib = p.g.in_ptr[focus]; ie = p.g.in_ptr[focus + 1]; total = p.g.tot_und[focus]; }
+        if (mode != 2) {
+            if (oe == ob) continue;          // neighbors.length == 0
+            if (total == 0) continue;        // totalWeight == 0 (directed version only)
+        }
+        const double spread = (1 - alpha) * wet;
+        const int32_t *idx0 = mode == 1 ? p.g.in_idx : p.g.out_idx;
+        const float *w0 = mode == 1 ? p.g.in_w : p.g.out_w;
+        for (int64_t k = ob; k < oe; k += 64) {
+            const int64_t kk = k + lane;
+            bool act = kk < oe; int32_t nb = 0; double pt = 0;
+            if (act) { nb = idx0[kk]; const float weight = w0[kk]; pt = spread * ((double)weight / total); act = !(pt < epsilon); }
+            if (!tree_add(act, nb, pt)) return false;
+        }
+        for (int64_t k = ib; k < ie; k += 64) {   // undirected: in-neighbours after the out-neighbours
+            const int64_t kk = k + lane;
+            bool act = kk < ie; int32_t nb = 0; double pt = 0;
+            if (act) { nb = p.g.in_idx[kk]; const float weight = p.g.in_w[kk]; pt = spread * ((double)weight / total); act = !(pt < epsilon); }
+            if (!tree_add(act, nb, pt)) return false;
+        }
+    }
+    return true;
+}
+
+// Float.compare-based max/min over a row (BCV.max / BCV.min)
+__device__ __forceinline__ int float_compare(float a, float b) {
+    if (a < b) return -1;
+    if (a > b) return 1;
+    const int ia = (a != a) ? 0x7fc00000 : __builtin_bit_cast(int, a);
+    const int ib = (b != b) ? 0x7fc00000 : __builtin_bit_cast(int, b);
+    return ia == ib ? 0 : (ia < ib ? -1 : 1);
+}
+
+__global__ __launch_bounds__(64) void k_bca(BcaParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x;
+    const BcaWork w = carve(p, wave);
+    // table starts empty
+    for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY;
+    wave_sync();
+    const int32_t n_rows = p.row_end - p.row_begin;
+
+    for (;;) {
+        unsigned long long ticket = 0;
+        if (lane == 0) ticket = atomicAdd(p.queue, 1ull);
+        const int32_t r = rfl((int)ticket);
+        if (r >= n_rows || ticket >= (unsigned long long)n_rows) break;
+        const int32_t bookmark = p.row_begin + r;
+        int32_t n_touched = 0, nf = 0, nr = 0;
+        int32_t status = 0;
+        bool ok = bca_pass(p, w, bookmark, p.directed ? 0 : 2, false, n_touched, nf, &status);
+        if (ok && p.directed) ok = bca_pass(p, w, bookmark, 1, true, n_touched, nr, &status);   // DirectedWeighted: reverse = true always
+        status = rfl(status);
+        int32_t n_out = 0; float row_max = 1.0f;
+        int64_t off = 0;
+        if (ok) {
+            // ---- reverse BCV iteration order + merge bookkeeping (directed) ----
+            int32_t M = 0, cap;
+            if (p.directed) {
+                const int32_t cap_r = java_cap_after_puts(nr);
+                // position of each reverse entry in the reverse map's iteration order: rank of (bin, seq)
+                for (int e = lane; e < n_touched; e += 64) {
+                    const int32_t s = w.touched[e];
+                    const int32_t sq = w.rseq[s];
+                    w.okey[e] = sq < 0 ? ~0ull : (((unsigned long long)(java_hash(w.hkey[s]) & (uint32_t)(cap_r - 1)) << 32) | (uint32_t)sq);
+                }
+                wave_sync();
+                for (int e = lane; e < n_touched; e += 64) {
+                    const unsigned long long me = w.okey[e];
+                    if (me == ~0ull) continue;
+                    int32_t rank = 0;
+                    for (int o = 0; o < n_touched; ++o) rank += w.okey[o] < me;
+                    const int32_t s = w.touched[e];
+                    w.rpos[rank] = s;
+                    w.rnew[rank] = w.fseq[s] < 0;
+                }
+                wave_sync();
+                // exclusive prefix of `new` over iteration positions -> merge sequence of new keys
+                int32_t running = 0;
+                for (int base = 0; base < nr; base += 64) {
+                    const int t = base + lane;
+                    const int32_t flag = t < nr ? w.rnew[t] : 0;
+                    const unsigned long long mk = __ballot(flag != 0);
+                    if (t < nr) w.rnew[t] = flag ? running + __popcll(mk & lanemask_lt()) : -1;
+                    running += __popcll(mk);
+                }
+                M = running;
+                wave_sync();
+                // size before the last merge() call decides the final capacity (resize happens BEFORE the lookup)
+                int32_t size_before_last = nf;
+                if (nr > 0) size_before_last = nf + M - (w.rnew[nr - 1] >= 0 ? 1 : 0);
+                cap = java_cap_after_puts(nf);
+                while (size_before_last > (cap / 4) * 3) cap <<= 1;
+                if (nr == 0) cap = java_cap_after_puts(nf);
+                // merged values; a key new to the forward map remembers its merge sequence m as fseq = -(m+2)
+                for (int t = lane; t < nr; t += 64) {
+                    const int32_t s = w.rpos[t];
+                    const int32_t m = w.rnew[t];
+                    if (m < 0) w.fval[s] = w.fval[s] + w.rval[s];                     // Float.sum(old, value)
+                    else { w.fval[s] = w.rval[s]; w.fseq[s] = -(m + 2); }
+                }
+                wave_sync();
+                n_out = nf + M;
+                // final order: bins ascending; inside a bin the merged-new keys (linked at the bin HEAD, so in
+                // reverse merge order) come before the forward keys (appended at the TAIL, in put order)
+                for (int e = lane; e < n_touched; e += 64) {
+                    const int32_t s = w.touched[e];
+                    const uint32_t bin = java_hash(w.hkey[s]) & (uint32_t)(cap - 1);
+                    const int32_t fs = w.fseq[s];
+                    unsigned long long key = ~0ull;
+                    if (fs >= 0) key = ((unsigned long long)bin << 33) | (1ull << 32) | (uint32_t)fs;
+                    else if (fs <= -2) key = ((unsigned long long)bin << 33) | (uint32_t)(M - 1 - (-fs - 2));
+                    w.okey[e] = key;
+                }
+                wave_sync();
+            } else {
+                cap = java_cap_after_puts(nf);
+                n_out = nf;
+                for (int e = lane; e < n_touched; e += 64) {
+                    const int32_t s = w.touched[e];
+                    const uint32_t bin = java_hash(w.hkey[s]) & (uint32_t)(cap - 1);
+                    w.okey[e] = w.fseq[s] >= 0 ? (((unsigned long long)bin << 33) | (uint32_t)w.fseq[s]) : ~0ull;
+                }
+                wave_sync();
+            }
+            const int32_t n_cand = n_touched;
+            // ---- normalisation needs the row in iteration order: rank every candidate ----
+            const bool drop_root = p.normalize != GE_NORM_NONE;
+            if (lane == 0) {
+                const unsigned long long o = atomicAdd(p.pool_used, (unsigned long long)n_out);
+                off = (int64_t)o;
+            }
+            off = ((int64_t)(unsigned)rfl((int)(off >> 32)) << 32) | (unsigned)rfl((int)(off & 0xFFFFFFFFll));
+            if (off + n_out > p.out_cap) { status = 3; ok = false; }
+            if (ok) {
+                for (int e = lane; e < n_cand; e += 64) {
+                    const unsigned long long me = w.okey[e];
+                    if (me == ~0ull) continue;
+                    int32_t rank = 0;
+                    for (int o = 0; o < n_cand; ++o) rank += w.okey[o] < me;
+                    const int32_t s = w.touched[e];
+                    p.outJ[off + rank] = w.hkey[s];
+                    p.outX[off + rank] = w.fval[s];
+                }
+                wave_sync();
+                __threadfence();
+                // ---- BCV.toUnity / toCounts (sequential float folds in iteration order), BCV.max ----
+                if (lane == 0) {
+                    int32_t *oj = p.outJ + off; float *ox = p.outX + off;
+                    int32_t n = n_out;
+                    if (p.normalize == GE_NORM_COUNTS) {
+                        float aMax = 1.0f, aMin = 0.0f;
+                        for (int k = 0; k < n; ++k) {
+                            const float v = __hip_atomic_load(ox + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (k == 0) { aMax = v; aMin = v; }
+                            else { aMax = float_compare(aMax, v) >= 0 ? aMax : v; aMin = float_compare(aMin, v) <= 0 ? aMin : v; }
+                        }
+                        for (int k = 0; k < n; ++k) {
+                            const float v = __hip_atomic_load(ox + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ox[k] = (v / ((aMax - aMin) / (1000.0f - 1.0f))) + 1.0f;
+                        }
+                    }
+                    if (drop_root) {                                   // remove(rootNode)
+                        int k = 0;
+                        while (k < n && __hip_atomic_load(oj + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != bookmark) ++k;
+                        for (int q = k; q + 1 < n; ++q) {
+                            oj[q] = __hip_atomic_load(oj + q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ox[q] = __hip_atomic_load(ox + q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (k < n) --n;
+                    }
+                    if (p.normalize == GE_NORM_UNITY) {
+                        float sum = 0.0f;
+                        for (int k = 0; k < n; ++k) {
+                            const float v = __hip_atomic_load(ox + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            sum = k == 0 ? v : sum + v;                // reduce(Float::sum)
+                        }
+                        for (int k = 0; k < n; ++k) ox[k] = __hip_atomic_load(ox + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / sum - 1e-6f;
+                    }
+                    float mx = 1.0f;                                   // max().orElse(1f)
+                    for (int k = 0; k < n; ++k) {
+                        const float v = __hip_atomic_load(ox + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        mx = k == 0 ? v : (float_compare(mx, v) >= 0 ? mx : v);
+                    }
+                    row_max = mx;
+                    n_out = n;
+                }
+                n_out = rfl(n_out);
+            }
+        }
+        if (lane == 0) {
+            p.row_n[r] = ok ? n_out : 0;
+            p.row_off[r] = off;
+            p.row_max[r] = row_max;
+            if (!ok) atomicMax(p.status, status ? status : 1);
+        }
+        // reset the table for the next bookmark
+        for (int e = lane; e < n_touched && e < p.hc / 2; e += 64) w.hkey[w.touched[e]] = KEY_EMPTY;
+        if (!ok && status == 1) for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY;   // touched[] was truncated
+        wave_sync();
+    }
+}
+
+// totalWeight per vertex, summed sequentially in neighbour order in fp64 exactly as the Java loops do
+// (DirectedWeighted.java:69-75; UndirectedWeighted.java:61-73: out-neighbours then in-neighbours into ONE accumulator).
+__global__ void k_totals(BcaGraph g, double *tot_out, double *tot_in, double *tot_und) {
+    const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.V) return;
+    double a = 0;
+    for (int64_t k = g.out_ptr[v]; k < g.out_ptr[v + 1]; ++k) a += g.out_w[k];
+    tot_out[v] = a;
+    double u = a;
+    double b = 0;
+    for (int64_t k = g.in_ptr[v]; k < g.in_ptr[v + 1]; ++k) { b += g.in_w[k]; u += g.in_w[k]; }
+    tot_in[v] = b;
+    tot_und[v] = u;
+}
+
+// rows from the pool -> bookmark order
+__global__ void k_gather_rows(const int32_t *poolJ, const float *poolX, const int64_t *row_off, const int32_t *row_n,
+                              const int64_t *dst_off, int32_t n_rows, int32_t row_begin,
+                              int32_t *I, int32_t *J, float *X) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x / 64;
+    for (int32_t r = blockIdx.x * wpb + (threadIdx.x >> 6); r < n_rows; r += gridDim.x * wpb) {
+        const int64_t so = row_off[r], d = dst_off[r];
+        const int32_t n = row_n[r];
+        for (int k = lane; k < n; k += 64) { I[d + k] = row_begin + r; J[d + k] = poolJ[so + k]; X[d + k] = poolX[so + k]; }
+    }
+}
+
+}  // namespace
+
+struct ge_coo {
+    int64_t nnz = 0;
+    int32_t V = 0;
+    std::vector<int32_t> I, J;
+    std::vector<float> X;
+    std::vector<int64_t> row_ptr;
+    double max = 0;
+};
+
+namespace {
+
+template <typename T>
+ge_status upload(const T *src, size_t n, T **dst) {
+    GE_HIP(hipMalloc((void **)dst, sizeof(T) * std::max<size_t>(n, 1)));
+    if (n) GE_HIP(hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice));
+    return GE_OK;
+}
+
+struct DevKeeper {      // frees every device buffer of one ge_bca_build call
+    std::vector<void *> ptrs;
+    ~DevKeeper() { for (void *q : ptrs) (void)hipFree(q); }
+    template <typename T> T *keep(T *q) { ptrs.push_back((void *)q); return q; }
+};
+
+// Math.max(double, double)
+double java_math_max(double a, double b) {
+    if (a != a) return a;
+    if (a == 0.0 && b == 0.0) return std::signbit(a) ? b : a;
+    return a >= b ? a : b;
+}
+
+}  // namespace
+
 extern "C" {
-ge_status ge_bca_build(const ge_csr *, const ge_csr *, const ge_bca_cfg *, ge_coo **result) {
-    if (result) *result = nullptr;
-    return ge::fail(GE_ERR_STATE, "ge_bca_build: device builder not built into this library yet");
+
+ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_bca_cfg *cfg, ge_coo **result) {
+    if (!result) return ge::fail(GE_ERR_ARG, "result is null");
+    *result = nullptr;
+    if (!out_nbrs || !in_nbrs || !cfg) return ge::fail(GE_ERR_ARG, "null argument");
+    const int32_t V = out_nbrs->num_vertices;
+    if (V <= 0 || in_nbrs->num_vertices != V) return ge::fail(GE_ERR_ARG, "out/in neighbourhoods must describe the same V > 0 vertices");
+    if (!(cfg->alpha > 0) || !(cfg->epsilon > 0))
+        return ge::fail(GE_ERR_ARG, "Invalid BCA parameters, alpha and epsilon are mandatory");       // Configuration.check
+    if (cfg->normalize < GE_NORM_NONE || cfg->normalize > GE_NORM_COUNTS) return ge::fail(GE_ERR_ARG, "invalid normalize %d", cfg->normalize);
+    if (!out_nbrs->ptr || !in_nbrs->ptr) return ge::fail(GE_ERR_ARG, "null CSR pointer array");
+    int32_t rb = cfg->row_begin, re = cfg->row_end;
+    if (rb == 0 && re == 0) re = V;
+    if (rb < 0 || re > V || rb >= re) return ge::fail(GE_ERR_ARG, "invalid bookmark range [%d,%d)", rb, re);
+    const int64_t Eo = out_nbrs->ptr[V], Ei = in_nbrs->ptr[V];
+    if (out_nbrs->ptr[0] != 0 || in_nbrs->ptr[0] != 0 || Eo < 0 || Ei < 0) return ge::fail(GE_ERR_ARG, "CSR offsets must start at 0");
+    for (int32_t v = 0; v < V; ++v)
+        if (out_nbrs->ptr[v + 1] < out_nbrs->ptr[v] || in_nbrs->ptr[v + 1] < in_nbrs->ptr[v]) return ge::fail(GE_ERR_ARG, "CSR offsets must be non-decreasing (vertex %d)", v);
+    if ((Eo && (!out_nbrs->idx || !out_nbrs->weight)) || (Ei && (!in_nbrs->idx || !in_nbrs->weight))) return ge::fail(GE_ERR_ARG, "null CSR index/weight array");
+    for (int64_t k = 0; k < Eo; ++k) if (out_nbrs->idx[k] < 0 || out_nbrs->idx[k] >= V) return ge::fail(GE_ERR_ARG, "out neighbour %lld = %d outside [0,%d)", (long long)k, out_nbrs->idx[k], V);
+    for (int64_t k = 0; k < Ei; ++k) if (in_nbrs->idx[k] < 0 || in_nbrs->idx[k] >= V) return ge::fail(GE_ERR_ARG, "in neighbour %lld = %d outside [0,%d)", (long long)k, in_nbrs->idx[k], V);
+    ge_status st = ge::select_device(cfg->device);
+    if (st != GE_OK) return st;
+
+    DevKeeper dev;
+
+    BcaParams p{};
+    int64_t *d_optr = nullptr, *d_iptr = nullptr; int32_t *d_oidx = nullptr, *d_iidx = nullptr; float *d_ow = nullptr, *d_iw = nullptr;
+    if ((st = upload(out_nbrs->ptr, (size_t)V + 1, &d_optr)) != GE_OK) return st; dev.keep(d_optr);
+    if ((st = upload(in_nbrs->ptr, (size_t)V + 1, &d_iptr)) != GE_OK) return st;  dev.keep(d_iptr);
+    if ((st = upload(out_nbrs->idx, (size_t)Eo, &d_oidx)) != GE_OK) return st;    dev.keep(d_oidx);
+    if ((st = upload(in_nbrs->idx, (size_t)Ei, &d_iidx)) != GE_OK) return st;     dev.keep(d_iidx);
+    if ((st = upload(out_nbrs->weight, (size_t)Eo, &d_ow)) != GE_OK) return st;   dev.keep(d_ow);
+    if ((st = upload(in_nbrs->weight, (size_t)Ei, &d_iw)) != GE_OK) return st;    dev.keep(d_iw);
+    double *d_tot = nullptr;
+    GE_HIP(hipMalloc((void **)&d_tot, sizeof(double) * 3 * (size_t)V)); dev.keep(d_tot);
+    p.g = BcaGraph{d_optr, d_iptr, d_oidx, d_iidx, d_ow, d_iw, d_tot, d_tot + V, d_tot + 2 * (size_t)V, V};
+    hipLaunchKernelGGL(k_totals, dim3((V + 255) / 256), dim3(256), 0, 0, p.g, d_tot, d_tot + V, d_tot + 2 * (size_t)V);
+    GE_HIP(hipGetLastError());
+
+    p.alpha = cfg->alpha; p.epsilon = cfg->epsilon; p.directed = cfg->directed ? 1 : 0; p.normalize = cfg->normalize;
+    p.row_begin = rb; p.row_end = re;
+    const int32_t n_rows = re - rb;
+
+    hipDeviceProp_t prop;
+    GE_HIP(hipGetDeviceProperties(&prop, cfg->device));
+    const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    int32_t *d_row_n = nullptr; int64_t *d_row_off = nullptr; float *d_row_max = nullptr;
+    GE_HIP(hipMalloc((void **)&d_row_n, sizeof(int32_t) * (size_t)n_rows)); dev.keep(d_row_n);
+    GE_HIP(hipMalloc((void **)&d_row_off, sizeof(int64_t) * (size_t)n_rows)); dev.keep(d_row_off);
+    GE_HIP(hipMalloc((void **)&d_row_max, sizeof(float) * (size_t)n_rows)); dev.keep(d_row_max);
+    unsigned long long *d_ctr = nullptr;    // [0] pool_used, [1] queue, then status word
+    GE_HIP(hipMalloc((void **)&d_ctr, 32)); dev.keep(d_ctr);
+    p.row_n = d_row_n; p.row_off = d_row_off; p.row_max = d_row_max;
+    p.pool_used = d_ctr; p.queue = d_ctr + 1; p.status = reinterpret_cast<int32_t *>(d_ctr + 2);
+
+    // capacities: the TreeMap never holds more than 1/epsilon nodes (every node in it carries >= epsilon of at
+    // most 1.0 paint); the table holds every node touched by the forward+reverse passes.  Both grow on overflow.
+    int64_t ac = (int64_t)std::min<double>((double)V, std::ceil(1.0 / cfg->epsilon) + 2.0) + 64;
+    int64_t hc = 2048;
+    while (hc < 4 * std::min<int64_t>(V, 256)) hc <<= 1;
+    int64_t pool_cap = std::max<int64_t>((int64_t)n_rows * 16, 1 << 16);
+    if (const char *e = std::getenv("GE_BCA_TABLE")) hc = std::max<int64_t>(64, std::atoll(e));
+    int32_t *d_pJ = nullptr; float *d_pX = nullptr; char *d_work = nullptr;
+    std::vector<int32_t> h_n((size_t)n_rows);
+    for (int attempt = 0;; ++attempt) {
+        if (attempt > 12) return ge::fail(GE_ERR_OVERFLOW, "BCA work buffers kept overflowing (table %lld, active list %lld, pool %lld)", (long long)hc, (long long)ac, (long long)pool_cap);
+        int hl = 0; while ((1ll << hl) < hc) ++hl;
+        hc = 1ll << hl;
+        const int64_t stride = (work_bytes(hc, ac) + 255) / 256 * 256;
+        int64_t n_waves = std::min<int64_t>((int64_t)cus * 16, n_rows);
+        while (n_waves > 1 && n_waves * stride > (int64_t)6 << 30) n_waves /= 2;
+        if (d_work) { (void)hipFree(d_work); d_work = nullptr; }
+        if (d_pJ) { (void)hipFree(d_pJ); d_pJ = nullptr; }
+        if (d_pX) { (void)hipFree(d_pX); d_pX = nullptr; }
+        hipError_t e1 = hipMalloc((void **)&d_work, (size_t)(n_waves * stride));
+        hipError_t e2 = hipMalloc((void **)&d_pJ, sizeof(int32_t) * (size_t)pool_cap);
+        hipError_t e3 = hipMalloc((void **)&d_pX, sizeof(float) * (size_t)pool_cap);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+            if (d_work) (void)hipFree(d_work);
+            if (d_pJ) (void)hipFree(d_pJ);
+            if (d_pX) (void)hipFree(d_pX);
+            return ge::fail(GE_ERR_OOM, "device allocation failed for BCA work buffers (table %lld slots x %lld waves, pool %lld)", (long long)hc, (long long)n_waves, (long long)pool_cap);
+        }
+        p.hc = (int32_t)hc; p.hc_log2 = hl; p.ac = (int32_t)ac; p.work = d_work; p.work_stride = stride;
+        p.outJ = d_pJ; p.outX = d_pX; p.out_cap = pool_cap;
+        hipError_t e = hipMemset(d_ctr, 0, 32);
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_bca, dim3((unsigned)n_waves), dim3(64), 0, 0, p); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        unsigned long long h_ctr[4] = {0, 0, 0, 0};
+        if (e == hipSuccess) e = hipMemcpy(h_ctr, d_ctr, 32, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_HIP, "BCA kernel failed: %s", hipGetErrorString(e)); }
+        const int32_t status = (int32_t)(h_ctr[2] & 0xFFFFFFFFull);
+        const int64_t used = (int64_t)h_ctr[0];
+        if (status == 0 && used <= pool_cap) break;
+        if (status == 1) hc *= 4;
+        else if (status == 2) ac = std::min<int64_t>(ac * 4, (int64_t)V + 64);
+        if (used > pool_cap || status == 3) pool_cap = std::max<int64_t>(used + used / 8 + 1024, pool_cap * 2);
+    }
+    dev.keep(d_work); dev.keep(d_pJ); dev.keep(d_pX);
+
+    ge_coo *c = new (std::nothrow) ge_coo();
+    if (!c) return ge::fail(GE_ERR_OOM, "host allocation failed");
+    c->V = V;
+    std::vector<float> h_max((size_t)n_rows);
+    hipError_t e = hipMemcpy(h_n.data(), d_row_n, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(h_max.data(), d_row_max, sizeof(float) * (size_t)n_rows, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { delete c; return ge::fail(GE_ERR_HIP, "copy back failed: %s", hipGetErrorString(e)); }
+    c->row_ptr.assign((size_t)V + 1, 0);
+    std::vector<int64_t> dst((size_t)n_rows);
+    int64_t total = 0;
+    for (int32_t v = 0; v < V; ++v) {
+        c->row_ptr[(size_t)v] = total;
+        if (v >= rb && v < re) { dst[(size_t)(v - rb)] = total; total += h_n[(size_t)(v - rb)]; }
+    }
+    c->row_ptr[(size_t)V] = total;
+    c->nnz = total;
+    // BookmarkColoring.setMax over bookmarks in completion (= ascending) order, J/bca/BookmarkColoring.java:97,162-164
+    double mx = 0;
+    for (int32_t r = 0; r < n_rows; ++r) mx = java_math_max(mx, (double)h_max[(size_t)r]);
+    c->max = mx;
+    c->I.resize((size_t)total); c->J.resize((size_t)total); c->X.resize((size_t)total);
+    if (total > 0) {
+        int64_t *d_dst = nullptr; int32_t *d_I = nullptr, *d_J = nullptr; float *d_X = nullptr;
+        bool good = hipMalloc((void **)&d_dst, sizeof(int64_t) * (size_t)n_rows) == hipSuccess; if (good) dev.keep(d_dst);
+        good = good && hipMalloc((void **)&d_I, sizeof(int32_t) * (size_t)total) == hipSuccess; if (d_I) dev.keep(d_I);
+        good = good && hipMalloc((void **)&d_J, sizeof(int32_t) * (size_t)total) == hipSuccess; if (d_J) dev.keep(d_J);
+        good = good && hipMalloc((void **)&d_X, sizeof(float) * (size_t)total) == hipSuccess;   if (d_X) dev.keep(d_X);
+        if (!good) { delete c; return ge::fail(GE_ERR_OOM, "device allocation failed for the COO (%lld entries)", (long long)total); }
+        e = hipMemcpy(d_dst, dst.data(), sizeof(int64_t) * (size_t)n_rows, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)std::min<int64_t>((n_rows + 3) / 4, 65535)), dim3(256), 0, 0,
+                               d_pJ, d_pX, d_row_off, d_row_n, d_dst, n_rows, rb, d_I, d_J, d_X);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(c->I.data(), d_I, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(c->J.data(), d_J, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(c->X.data(), d_X, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { delete c; return ge::fail(GE_ERR_HIP, "COO gather failed: %s", hipGetErrorString(e)); }
+    }
+    *result = c;
+    return GE_OK;
 }
-ge_status ge_coo_get(const ge_coo *, int64_t *, const int32_t **, const int32_t **, const float **, const int64_t **, double *) {
-    return ge::fail(GE_ERR_STATE, "ge_coo_get: device builder not built into this library yet");
+
+ge_status ge_coo_get(const ge_coo *c, int64_t *nnz, const int32_t **I, const int32_t **J, const float **X,
+                     const int64_t **row_ptr, double *max) {
+    if (!c) return ge::fail(GE_ERR_ARG, "null ge_coo handle");
+    if (nnz) *nnz = c->nnz;
+    if (I) *I = c->I.data();
+    if (J) *J = c->J.data();
+    if (X) *X = c->X.data();
+    if (row_ptr) *row_ptr = c->row_ptr.data();
+    if (max) *max = c->max;
+    return GE_OK;
 }
-void ge_coo_destroy(ge_coo *) {}
-}
+
+void ge_coo_destroy(ge_coo *c) { delete c; }
+
+}  // extern "C"
