@@ -1,0 +1,693 @@
+// ge_host.hpp -- C++ host side above the C ABI, mirroring the reference's operator interfaces for the
+// hot path (the reference is compiled Java; no JDK exists in the build image, so the host that a
+// Java maintainer would write over JNI -- see INTEGRATION.md -- is restated here in C++).
+//
+//   Configuration / check / InvalidConfigurationException   J/util/config/Configuration.java, J/util/read/ConfigReader.java
+//   CoOccurrenceMatrix, BookmarkColoring                    J/util/CoOccurrenceMatrix.java:6-17, J/bca/BookmarkColoring.java
+//   IOptimizer, Adagrad, Optimum, CostFunction choice       J/opt/IOptimizer.java, J/opt/grad/Adagrad.java, J/opt/Optimizer.java:66-120
+//   EmbeddingTextWriter                                     J/util/write/EmbeddingTextWriter.java
+//   Main.createFileName / createOptimizer / runProgram      J/Main.java:29-131
+//   N-Triples graph ingest with Rdf2GrphConverter's vertex/edge rules   J/convert/Rdf2GrphConverter.java:71-114,195-241
+// (J/ = src/main/java/org/uu/nl/embedding/).  All numeric work goes through libgeglove.so.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <filesystem>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/geglove.h"
+
+namespace ge_host {
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+struct InvalidConfigurationException : std::runtime_error {     // Configuration.java:496-500
+    explicit InvalidConfigurationException(const std::string &m) : std::runtime_error("Invalid configuration: " + m) {}
+};
+struct NativeError : std::runtime_error {
+    ge_status status;
+    NativeError(ge_status s, const std::string &what) : std::runtime_error(what), status(s) {}
+};
+inline void check(ge_status s) {
+    if (s != GE_OK) throw NativeError(s, std::string("geglove error ") + std::to_string(s) + ": " + ge_last_error());
+}
+
+// ------------------------------------------------------------------------------------------------
+// Java number -> string conversions used by the writer header and the file name
+// ------------------------------------------------------------------------------------------------
+inline std::string shortest_digits(double a, int max_prec, int &exp10) {   // digits d1d2..., value = 0.d1d2.. * 10^(exp10+1)
+    char buf[64];
+    int prec = 0;
+    for (; prec <= max_prec; ++prec) {
+        std::snprintf(buf, sizeof buf, "%.*e", prec, a);
+        if (max_prec == 8 ? (float)std::strtod(buf, nullptr) == (float)a : std::strtod(buf, nullptr) == a) break;
+    }
+    const char *e = std::strchr(buf, 'e');
+    exp10 = std::atoi(e + 1);
+    std::string d;
+    for (const char *q = buf; q < e; ++q) if (*q >= '0' && *q <= '9') d.push_back(*q);
+    while (d.size() > 1 && d.back() == '0') d.pop_back();
+    return d;
+}
+// Double.toString / Float.toString: decimal for 1e-3 <= |x| < 1e7, otherwise d.dddE[-]n
+inline std::string java_number(double v, bool is_float) {
+    if (v != v) return "NaN";
+    if (std::isinf(v)) return v > 0 ? "Infinity" : "-Infinity";
+    if (v == 0) return std::signbit(v) ? "-0.0" : "0.0";
+    int ex;
+    const std::string d = shortest_digits(std::fabs(v), is_float ? 8 : 17, ex);
+    std::string out = v < 0 ? "-" : "";
+    if (ex >= -3 && ex < 7) {
+        if (ex < 0) { out += "0."; out.append((size_t)(-ex - 1), '0'); out += d; }
+        else {
+            for (int k = 0; k <= ex; ++k) out.push_back(k < (int)d.size() ? d[(size_t)k] : '0');
+            out.push_back('.');
+            if ((int)d.size() > ex + 1) out += d.substr((size_t)ex + 1); else out.push_back('0');
+        }
+    } else {
+        out.push_back(d[0]); out.push_back('.');
+        if (d.size() > 1) out += d.substr(1); else out.push_back('0');
+        out += "E" + std::to_string(ex);
+    }
+    return out;
+}
+// String.format("%11.6E", v): HALF_UP on the shortest repr digits (EmbeddingTextWriter.java:134)
+inline std::string java_format_11_6E(double v) {
+    if (v != v) return "        NaN";
+    char body[48];
+    if (std::isinf(v)) { std::snprintf(body, sizeof body, "%11s", v > 0 ? "Infinity" : "-Infinity"); return body; }
+    int ex = 0;
+    std::string d = v == 0 ? std::string("0") : shortest_digits(std::fabs(v), 17, ex);
+    int dig[7];
+    for (int k = 0; k < 7; ++k) dig[k] = k < (int)d.size() ? d[(size_t)k] - '0' : 0;
+    if (d.size() > 7 && d[7] >= '5') {
+        int k = 6;
+        while (k >= 0) { if (++dig[k] < 10) break; dig[k] = 0; --k; }
+        if (k < 0) { dig[0] = 1; for (int q = 1; q < 7; ++q) dig[q] = 0; ++ex; }
+    }
+    std::snprintf(body, sizeof body, "%s%d.%d%d%d%d%d%dE%c%02d", std::signbit(v) ? "-" : "", dig[0], dig[1], dig[2], dig[3],
+                  dig[4], dig[5], dig[6], ex < 0 ? '-' : '+', ex < 0 ? -ex : ex);
+    char out[64];
+    std::snprintf(out, sizeof out, "%11s", body);
+    return out;
+}
+
+// ------------------------------------------------------------------------------------------------
+// YAML subset: block maps, block lists ("- "), flow lists [a, b], scalars, comments.  That is all
+// dblp/onstage/saa.config.yml use.  A '#' starts a comment only at line start or after whitespace
+// (predicate URIs contain '#').
+// ------------------------------------------------------------------------------------------------
+struct YNode {
+    enum Kind { Null, Scalar, Map, List } kind = Null;
+    std::string scalar;
+    std::vector<std::pair<std::string, YNode>> map;     // insertion order kept (SnakeYAML builds a LinkedHashMap)
+    std::vector<YNode> list;
+    const YNode *get(const std::string &k) const {
+        for (auto &kv : map) if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+};
+namespace detail {
+inline std::string trim(const std::string &s) {
+    size_t a = 0, b = s.size();
+    while (a < b && (s[a] == ' ' || s[a] == '\t' || s[a] == '\r')) ++a;
+    while (b > a && (s[b - 1] == ' ' || s[b - 1] == '\t' || s[b - 1] == '\r')) --b;
+    return s.substr(a, b - a);
+}
+inline std::string unquote(std::string s) {
+    s = trim(s);
+    if (s.size() >= 2 && ((s.front() == '"' && s.back() == '"') || (s.front() == '\'' && s.back() == '\''))) return s.substr(1, s.size() - 2);
+    return s;
+}
+inline std::string strip_comment(const std::string &l) {
+    bool sq = false, dq = false;
+    for (size_t k = 0; k < l.size(); ++k) {
+        if (l[k] == '\'' && !dq) sq = !sq;
+        else if (l[k] == '"' && !sq) dq = !dq;
+        else if (l[k] == '#' && !sq && !dq && (k == 0 || l[k - 1] == ' ' || l[k - 1] == '\t')) return l.substr(0, k);
+    }
+    return l;
+}
+struct Line { int indent; std::string text; };
+inline YNode parse_value_inline(const std::string &v) {
+    YNode n;
+    const std::string t = trim(v);
+    if (!t.empty() && t.front() == '[' && t.back() == ']') {
+        n.kind = YNode::List;
+        std::string inner = t.substr(1, t.size() - 2), item;
+        std::stringstream ss(inner);
+        while (std::getline(ss, item, ',')) { item = unquote(item); if (!item.empty()) { YNode c; c.kind = YNode::Scalar; c.scalar = item; n.list.push_back(c); } }
+        return n;
+    }
+    n.kind = YNode::Scalar; n.scalar = unquote(t);
+    if (n.scalar == "~" || n.scalar == "null") { n.kind = YNode::Null; n.scalar.clear(); }
+    return n;
+}
+inline bool split_key(const std::string &t, std::string &key, std::string &val) {
+    size_t pos = std::string::npos;
+    for (size_t k = 0; k < t.size(); ++k)
+        if (t[k] == ':' && (k + 1 == t.size() || t[k + 1] == ' ' || t[k + 1] == '\t')) { pos = k; break; }
+    if (pos == std::string::npos) return false;
+    key = unquote(t.substr(0, pos)); val = trim(t.substr(pos + 1));
+    return true;
+}
+inline YNode parse_block(const std::vector<Line> &L, size_t &i, int indent) {
+    YNode n;
+    if (i >= L.size()) return n;
+    const bool is_list = L[i].text.rfind("- ", 0) == 0 || L[i].text == "-";
+    n.kind = is_list ? YNode::List : YNode::Map;
+    while (i < L.size() && L[i].indent == indent) {
+        std::string t = L[i].text;
+        if (is_list) {
+            if (!(t.rfind("- ", 0) == 0 || t == "-")) break;
+            std::string rest = t.size() > 2 ? trim(t.substr(2)) : "";
+            std::string k, v;
+            if (!rest.empty() && split_key(rest, k, v)) {
+                // "- key: value" opens a map whose further keys are indented by indent+2
+                std::vector<Line> sub;
+                sub.push_back({indent + 2, rest});
+                size_t j = i + 1;
+                while (j < L.size() && L[j].indent > indent) { sub.push_back(L[j]); ++j; }
+                size_t si = 0;
+                n.list.push_back(parse_block(sub, si, indent + 2));
+                i = j;
+            } else { n.list.push_back(parse_value_inline(rest)); ++i; }
+        } else {
+            std::string k, v;
+            if (!split_key(t, k, v)) throw InvalidConfigurationException("cannot parse line: " + t);
+            ++i;
+            if (!v.empty()) n.map.push_back({k, parse_value_inline(v)});
+            else if (i < L.size() && L[i].indent > indent) { const int ci = L[i].indent; n.map.push_back({k, parse_block(L, i, ci)}); }
+            else n.map.push_back({k, YNode()});
+        }
+    }
+    return n;
+}
+}  // namespace detail
+inline YNode parse_yaml(std::istream &in) {
+    std::vector<detail::Line> L;
+    std::string line;
+    while (std::getline(in, line)) {
+        line = detail::strip_comment(line);
+        size_t a = 0; while (a < line.size() && line[a] == ' ') ++a;
+        const std::string t = detail::trim(line);
+        if (t.empty() || t == "---") continue;
+        L.push_back({(int)a, t});
+    }
+    size_t i = 0;
+    if (L.empty()) return YNode();
+    return detail::parse_block(L, i, L[0].indent);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Configuration (tolerant bean)
+// ------------------------------------------------------------------------------------------------
+struct Configuration {
+    std::string graph, method;
+    int dim = 0, threads = 0;
+    std::vector<std::pair<std::string, float>> weights;
+    bool has_weights = false;
+    std::vector<std::map<std::string, std::string>> similarity;
+    struct { double alpha = 0, epsilon = 0; bool directed = false; std::string normalize; bool present = false; } bca;
+    struct { std::string method = "adagrad"; double tolerance = 0; int maxiter = 0; } opt;
+    struct { bool present = false; double variance = 0; } pca;
+    struct Output { bool present = false; std::string name; bool has_uri = false, has_blank = false, has_predicate = false, has_literal = false;
+                    std::vector<std::string> uri, blank, predicate, literal; } output;
+    // new, optional block `device:` (never changes the meaning of a reference key)
+    struct { std::string mode = "hogwild", shuffle = "device", hot = "auto"; long long seed = 0; bool has_seed = false; int id = 0; int workers = 0; } device;
+    std::vector<std::string> ignored_keys;     // legacy keys of the shipped YAMLs that the bean does not know
+
+    int getThreads() const {       // Configuration.java:71-73
+        if (threads != 0) return threads;
+        const unsigned hc = std::thread::hardware_concurrency();
+        return std::max(1, (int)hc - 1);
+    }
+    std::string getNormalize() const { return bca.normalize.empty() ? "none" : bca.normalize; }
+    bool usingPca() const { return pca.present; }
+    bool usingWeights() const { return has_weights && !weights.empty(); }
+    bool usingSimilarity() const { return !similarity.empty(); }
+
+    static double num(const YNode *n, double def = 0) { return (n && n->kind == YNode::Scalar) ? std::strtod(n->scalar.c_str(), nullptr) : def; }
+    static std::string str(const YNode *n) { return (n && n->kind == YNode::Scalar) ? n->scalar : std::string(); }
+    static bool boolean(const YNode *n) { const std::string s = str(n); return s == "true" || s == "True" || s == "yes" || s == "on"; }
+    static void strlist(const YNode *n, bool &present, std::vector<std::string> &out) {
+        if (!n) return;
+        present = n->kind != YNode::Null;
+        if (n->kind == YNode::List) for (auto &c : n->list) out.push_back(c.scalar);
+        else if (n->kind == YNode::Scalar && !n->scalar.empty()) out.push_back(n->scalar);
+        if (n->kind == YNode::Null) present = false;
+    }
+
+    static Configuration load(const std::string &path) {       // ConfigReader.load
+        std::ifstream f(path);
+        if (!f) throw std::runtime_error("Cannot find configuration file + " + path);
+        const YNode root = parse_yaml(f);
+        Configuration c;
+        if (root.kind != YNode::Map) throw InvalidConfigurationException("top level must be a mapping");
+        for (auto &kv : root.map) {
+            const std::string &k = kv.first; const YNode &v = kv.second;
+            if (k == "graph") c.graph = v.scalar;
+            else if (k == "method") c.method = v.scalar;
+            else if (k == "dim") c.dim = (int)num(&v);
+            else if (k == "threads") c.threads = (int)num(&v);
+            else if (k == "weights") { c.has_weights = true; for (auto &w : v.map) c.weights.push_back({w.first, (float)num(&w.second)}); }
+            else if (k == "similarity") {
+                for (auto &item : v.list) {
+                    std::map<std::string, std::string> m;
+                    for (auto &q : item.map) m[q.first] = q.second.scalar;
+                    if (m.count("predicate")) {      // legacy key of the shipped YAMLs: source = target
+                        if (!m.count("sourcePredicate")) m["sourcePredicate"] = m["predicate"];
+                        if (!m.count("targetPredicate")) m["targetPredicate"] = m["predicate"];
+                    }
+                    c.similarity.push_back(m);
+                }
+            } else if (k == "bca") {
+                c.bca.present = true;
+                for (auto &q : v.map) {
+                    if (q.first == "alpha") c.bca.alpha = num(&q.second);
+                    else if (q.first == "epsilon") c.bca.epsilon = num(&q.second);
+                    else if (q.first == "directed") c.bca.directed = boolean(&q.second);
+                    else if (q.first == "normalize") c.bca.normalize = q.second.scalar;
+                    else c.ignored_keys.push_back("bca." + q.first);           // bca.reverse, bca.predicates
+                }
+            } else if (k == "opt") {
+                for (auto &q : v.map) {
+                    if (q.first == "method") c.opt.method = q.second.scalar;
+                    else if (q.first == "tolerance") c.opt.tolerance = num(&q.second);
+                    else if (q.first == "maxiter") c.opt.maxiter = (int)num(&q.second);
+                    else c.ignored_keys.push_back("opt." + q.first);
+                }
+            } else if (k == "pca") { c.pca.present = true; c.pca.variance = num(v.get("variance")); }
+            else if (k == "output") {
+                c.output.present = true;
+                c.output.name = str(v.get("name"));
+                strlist(v.get("uri"), c.output.has_uri, c.output.uri);
+                strlist(v.get("blank"), c.output.has_blank, c.output.blank);
+                strlist(v.get("predicate"), c.output.has_predicate, c.output.predicate);
+                strlist(v.get("literal"), c.output.has_literal, c.output.literal);
+                // an explicitly empty flow list `uri: []` counts as "present" (outputUriNodes() is `uri != null`)
+                for (auto &q : v.map) if (q.second.kind == YNode::List && q.second.list.empty()) {
+                    if (q.first == "uri") c.output.has_uri = true; else if (q.first == "blank") c.output.has_blank = true;
+                    else if (q.first == "predicate") c.output.has_predicate = true; else if (q.first == "literal") c.output.has_literal = true;
+                }
+            } else if (k == "device") {
+                for (auto &q : v.map) {
+                    if (q.first == "mode") c.device.mode = q.second.scalar;
+                    else if (q.first == "shuffle") c.device.shuffle = q.second.scalar;
+                    else if (q.first == "hot") c.device.hot = q.second.scalar;
+                    else if (q.first == "seed") { c.device.seed = std::strtoll(q.second.scalar.c_str(), nullptr, 10); c.device.has_seed = true; }
+                    else if (q.first == "id") c.device.id = (int)num(&q.second);
+                    else if (q.first == "workers") c.device.workers = (int)num(&q.second);
+                }
+            } else c.ignored_keys.push_back(k);
+        }
+        return c;
+    }
+
+    static void check(const Configuration &c) {      // Configuration.check, same order and messages
+        const bool hasBca = c.bca.present && c.bca.alpha > 0 && c.bca.epsilon > 0;
+        const bool hasOut = c.output.present && (c.output.has_predicate || c.output.has_blank || c.output.has_uri || c.output.has_literal);
+        if (!(c.dim > 0)) throw InvalidConfigurationException("No dimension specified");
+        if (c.graph.empty()) throw InvalidConfigurationException("No input graph specified");
+        if (c.method.empty()) throw InvalidConfigurationException("Invalid method, choose one of: glove, pglove");
+        if (!hasBca) throw InvalidConfigurationException("Invalid BCA parameters, alpha and epsilon are mandatory");
+        if (!hasOut) throw InvalidConfigurationException("Invalid output parameters, specify at least one group");
+    }
+
+    static std::string similarity_to_string(const std::map<std::string, std::string> &m) {     // SimilarityGroup.toString
+        auto g = [&](const char *k, const char *def = "") { auto it = m.find(k); return it == m.end() ? std::string(def) : it->second; };
+        std::string method = g("method");
+        std::string up = method; for (auto &ch : up) ch = (char)std::toupper((unsigned char)ch);
+        std::string out = g("sourcePredicate") + " -> " + g("targetPredicate") + "\n method:" + method + ", threshold: " +
+                          java_number(std::strtod(g("threshold", "0").c_str(), nullptr), false);
+        const std::string smooth = java_number(m.count("smooth") && std::strtod(g("smooth").c_str(), nullptr) != 0 ? std::strtod(g("smooth").c_str(), nullptr) : 1.0, false);
+        if (up == "NGRAM_COSINE" || up == "NGRAM_JACCARD") return out + ", ngram: " + (m.count("ngram") && std::atoi(g("ngram").c_str()) ? g("ngram") : std::string("3"));
+        if (up == "NUMERIC") return out + ", smooth: " + smooth;
+        if (up == "DATE_DAYS" || up == "DATE_MONTHS" || up == "DATE_YEARS")
+            return out + ", pattern:" + g("pattern", "iso") + ", smooth: " + smooth + ", time: " + g("time", "bidirectional");
+        return out;
+    }
+
+    // the settings banner: Main.runProgram's log lines == EmbeddingTextWriter.writeConfig's header (with `prefix`)
+    std::vector<std::string> banner() const {
+        std::vector<std::string> L;
+        L.push_back("Starting the embedding creation process with following settings:");
+        L.push_back("Graph File: " + graph);
+        L.push_back("Embedding dimensions: " + std::to_string(dim));
+        L.push_back("Threads: " + std::to_string(getThreads()));
+        L.push_back("BCA Alpha: " + java_number(bca.alpha, false));
+        L.push_back("BCA Epsilon: " + java_number(bca.epsilon, false));
+        L.push_back(std::string("BCA Directed: ") + (bca.directed ? "true" : "false"));
+        L.push_back("BCA normalize: " + getNormalize());
+        L.push_back("Gradient Descent Algorithm: " + opt.method);
+        L.push_back(method + " Tolerance: " + java_number(opt.tolerance, false));
+        L.push_back(method + " Maximum Iterations: " + std::to_string(opt.maxiter));
+        if (usingPca()) L.push_back("PCA Minimum Variance: " + java_number(pca.variance, false)); else L.push_back("No PCA will be performed");
+        if (usingWeights()) {
+            L.push_back("Using weights, predicates that are not listed are ignored:");
+            for (auto &w : weights) L.push_back(w.first + ": " + java_number(w.second, true));
+        } else L.push_back("No weights specified, using linear weight");
+        if (usingSimilarity()) {
+            L.push_back("Using the following similarity metrics:");
+            for (auto &s : similarity) L.push_back(similarity_to_string(s));
+        } else L.push_back("No similarity matching will be performed");
+        return L;
+    }
+};
+
+// Main.createFileName (J/Main.java:80-105)
+inline std::string createFileName(const Configuration &c) {
+    std::string name = c.graph;
+    const size_t slash = name.find_last_of("/\\");
+    if (slash != std::string::npos) name = name.substr(slash + 1);
+    for (auto &ch : name) ch = (char)std::tolower((unsigned char)ch);
+    const size_t dot = name.rfind('.');
+    if (dot != std::string::npos) name = name.substr(0, dot);
+    std::string m = c.method; for (auto &ch : m) ch = (char)std::tolower((unsigned char)ch);
+    name += "_" + m;
+    name += c.usingSimilarity() ? "_partial" : "_exact";
+    name += c.bca.directed ? "_directed" : "_undirected";
+    name += "_" + java_number(c.bca.alpha, false) + "_" + java_number(c.bca.epsilon, false);
+    name += "_" + c.opt.method;
+    name += (c.usingPca() ? "_pca_" : "_") + std::to_string(c.dim);
+    return name;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Graph ingest: N-Triples subset with Rdf2GrphConverter's rules (the reference reads through Jena;
+// Jena is out of scope).  Vertex ids = order of first appearance in the file.
+// ------------------------------------------------------------------------------------------------
+enum NodeInfo : int8_t { URI = 0, BLANK = 1, LITERAL = 2 };     // J/convert/util/NodeInfo.java
+
+struct InMemoryGraph {
+    int32_t V = 0;
+    std::vector<std::string> keys;       // vertex label property (dictionary)
+    std::vector<int8_t> types;           // vertex type property
+    std::vector<int64_t> out_ptr, in_ptr;
+    std::vector<int32_t> out_idx, in_idx;
+    std::vector<float> out_w, in_w;
+    long long triples = 0, skipped = 0;
+};
+
+namespace detail {
+struct Term { std::string text; int8_t type; };
+inline bool read_term(const std::string &l, size_t &pos, Term &t) {
+    while (pos < l.size() && (l[pos] == ' ' || l[pos] == '\t')) ++pos;
+    if (pos >= l.size()) return false;
+    if (l[pos] == '<') {
+        const size_t e = l.find('>', pos);
+        if (e == std::string::npos) return false;
+        t.text = l.substr(pos + 1, e - pos - 1); t.type = URI; pos = e + 1; return true;
+    }
+    if (l[pos] == '_' && pos + 1 < l.size() && l[pos + 1] == ':') {
+        size_t e = pos; while (e < l.size() && l[e] != ' ' && l[e] != '\t') ++e;
+        t.text = l.substr(pos + 2, e - pos - 2); t.type = BLANK; pos = e; return true;
+    }
+    if (l[pos] == '"') {
+        std::string lex; size_t e = pos + 1;
+        while (e < l.size() && l[e] != '"') {
+            if (l[e] == '\\' && e + 1 < l.size()) { const char c = l[e + 1]; lex.push_back(c == 'n' ? '\n' : c == 't' ? '\t' : c == 'r' ? '\r' : c); e += 2; }
+            else lex.push_back(l[e++]);
+        }
+        if (e >= l.size()) return false;
+        ++e;
+        std::string suffix;
+        if (e < l.size() && l[e] == '@') { size_t q = e; while (q < l.size() && l[q] != ' ' && l[q] != '\t') ++q; suffix = l.substr(e, q - e); e = q; }
+        else if (e + 1 < l.size() && l[e] == '^' && l[e + 1] == '^') {
+            const size_t a = l.find('<', e), b = l.find('>', e);
+            if (a == std::string::npos || b == std::string::npos) return false;
+            const std::string dt = l.substr(a + 1, b - a - 1);
+            if (dt != "http://www.w3.org/2001/XMLSchema#string") suffix = "^^" + dt;      // Node.toString(false) form
+            e = b + 1;
+        }
+        t.text = lex + suffix; t.type = LITERAL; pos = e; return true;
+    }
+    return false;
+}
+}  // namespace detail
+
+inline void edges_to_csr(int32_t V, const std::vector<int32_t> &src, const std::vector<int32_t> &dst, const std::vector<float> &w,
+                         std::vector<int64_t> &ptr, std::vector<int32_t> &idx, std::vector<float> &wt) {
+    // unique neighbours per row, ascending id, first edge in input order wins (getEdge returns the first match)
+    std::vector<size_t> order(src.size());
+    for (size_t k = 0; k < order.size(); ++k) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return src[a] != src[b] ? src[a] < src[b] : dst[a] < dst[b]; });
+    ptr.assign((size_t)V + 1, 0); idx.clear(); wt.clear();
+    for (size_t q = 0; q < order.size(); ++q) {
+        const size_t k = order[q];
+        if (q > 0 && src[order[q - 1]] == src[k] && dst[order[q - 1]] == dst[k]) continue;
+        idx.push_back(dst[k]); wt.push_back(w[k]); ++ptr[(size_t)src[k] + 1];
+    }
+    for (int32_t v = 0; v < V; ++v) ptr[(size_t)v + 1] += ptr[(size_t)v];
+}
+
+inline InMemoryGraph read_ntriples(const std::string &path, const Configuration &cfg) {
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("Cannot read graph file " + path);
+    const std::string ext = path.size() > 3 ? path.substr(path.rfind('.') == std::string::npos ? 0 : path.rfind('.')) : "";
+    if (ext != ".nt" && ext != ".ntriples")
+        throw std::runtime_error("graph file " + path + ": only N-Triples (.nt) is read natively (the reference parses ttl/trig/hdt through Jena, which is out of scope); convert the file first");
+    InMemoryGraph g;
+    std::unordered_map<std::string, int32_t> vertexMap;                                      // non-literals
+    std::unordered_map<std::string, std::unordered_map<std::string, int32_t>> predLit;       // literals merged PER PREDICATE (:202-213)
+    std::unordered_map<std::string, float> weight;
+    const bool weighting = cfg.usingWeights();
+    for (auto &w : cfg.weights) weight[w.first] = w.second;
+    std::vector<int32_t> src, dst; std::vector<float> wt;
+    auto addVertex = [&](const std::string &pred, const detail::Term &n) -> int32_t {     // Rdf2GrphConverter.addVertex
+        if (n.type != LITERAL) {
+            auto it = vertexMap.find((n.type == BLANK ? "_:" : "") + n.text);
+            if (it != vertexMap.end()) return it->second;
+        } else {
+            auto &m = predLit[pred];
+            auto it = m.find(n.text);
+            if (it != m.end()) return it->second;
+            m[n.text] = g.V;
+        }
+        if (n.type != LITERAL) vertexMap[(n.type == BLANK ? "_:" : "") + n.text] = g.V;
+        g.keys.push_back(n.text); g.types.push_back(n.type);
+        return g.V++;
+    };
+    std::string line;
+    while (std::getline(f, line)) {
+        size_t pos = 0;
+        while (pos < line.size() && (line[pos] == ' ' || line[pos] == '\t')) ++pos;
+        if (pos >= line.size() || line[pos] == '#') continue;
+        detail::Term s, p, o;
+        if (!detail::read_term(line, pos, s) || !detail::read_term(line, pos, p) || !detail::read_term(line, pos, o)) continue;
+        ++g.triples;
+        float w = 1.0f;
+        if (weighting) {                                     // "Ignore unweighted predicates" (:84-90)
+            auto it = weight.find(p.text);
+            if (it == weight.end()) { ++g.skipped; continue; }
+            w = it->second;
+        }
+        const int32_t si = addVertex(p.text, s), oi = addVertex(p.text, o);
+        src.push_back(si); dst.push_back(oi); wt.push_back(w);
+    }
+    edges_to_csr(g.V, src, dst, wt, g.out_ptr, g.out_idx, g.out_w);
+    edges_to_csr(g.V, dst, src, wt, g.in_ptr, g.in_idx, g.in_w);
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CoOccurrenceMatrix / BookmarkColoring
+// ------------------------------------------------------------------------------------------------
+struct CoOccurrenceMatrix {                     // J/util/CoOccurrenceMatrix.java:6-17
+    virtual ~CoOccurrenceMatrix() = default;
+    virtual int vocabSize() const = 0;
+    virtual double max() const = 0;
+    virtual std::string getKey(int index) const = 0;
+    virtual int8_t getType(int index) const = 0;
+    virtual int cIdx_I(int i) const = 0;
+    virtual int cIdx_J(int j) const = 0;
+    virtual float cIdx_C(int i) const = 0;
+    virtual int coOccurrenceCount() const = 0;
+    virtual void shuffle() = 0;
+    // flat views for the native trainer (pre-shuffle order)
+    virtual const int32_t *dataI() const = 0;
+    virtual const int32_t *dataJ() const = 0;
+    virtual const float *dataX() const = 0;
+};
+
+class BookmarkColoring : public CoOccurrenceMatrix {        // J/bca/BookmarkColoring.java
+public:
+    BookmarkColoring(const InMemoryGraph &graph, const Configuration &config) : graph_(graph) {
+        ge_csr out{graph.V, graph.out_ptr.data(), graph.out_idx.data(), graph.out_w.data()};
+        ge_csr in{graph.V, graph.in_ptr.data(), graph.in_idx.data(), graph.in_w.data()};
+        ge_bca_cfg cfg{};
+        cfg.alpha = config.bca.alpha; cfg.epsilon = config.bca.epsilon; cfg.directed = config.bca.directed ? 1 : 0;
+        std::string n = config.getNormalize(); for (auto &ch : n) ch = (char)std::tolower((unsigned char)ch);
+        if (n == "none") cfg.normalize = GE_NORM_NONE; else if (n == "unity") cfg.normalize = GE_NORM_UNITY;
+        else if (n == "counts") cfg.normalize = GE_NORM_COUNTS; else throw std::invalid_argument("No enum constant BCANormalization." + n);
+        cfg.device = config.device.id;
+        ge_coo *h = nullptr;
+        check(ge_bca_build(&out, &in, &cfg, &h));
+        coo_.reset(h);
+        check(ge_coo_get(h, &nnz_, &I_, &J_, &X_, nullptr, &max_));
+    }
+    int vocabSize() const override { return graph_.V; }
+    double max() const override { return max_; }
+    std::string getKey(int index) const override { return graph_.keys[(size_t)index]; }
+    int8_t getType(int index) const override { return graph_.types[(size_t)index]; }
+    int cIdx_I(int i) const override { return I_[i]; }
+    int cIdx_J(int j) const override { return J_[j]; }
+    float cIdx_C(int i) const override { return X_[i]; }
+    int coOccurrenceCount() const override { return (int)nnz_; }
+    void shuffle() override {}                  // the permutation is part of the native trainer's RNG stream
+    const int32_t *dataI() const override { return I_; }
+    const int32_t *dataJ() const override { return J_; }
+    const float *dataX() const override { return X_; }
+private:
+    struct Del { void operator()(ge_coo *c) const { ge_coo_destroy(c); } };
+    const InMemoryGraph &graph_;
+    std::unique_ptr<ge_coo, Del> coo_;
+    int64_t nnz_ = 0; const int32_t *I_ = nullptr, *J_ = nullptr; const float *X_ = nullptr; double max_ = 0;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Optimizer
+// ------------------------------------------------------------------------------------------------
+struct Optimum {                                 // J/opt/Optimum.java
+    double finalCost = 0;
+    std::vector<double> result;
+    std::vector<double> costHistory;
+};
+struct IOptimizer {                              // J/opt/IOptimizer.java:6-11
+    virtual ~IOptimizer() = default;
+    virtual Optimum optimize() = 0;
+    virtual std::string getName() const = 0;
+    virtual std::vector<double> extractResult() = 0;
+};
+enum class CostFunction { GLOVE, PGLOVE };       // GloveCost / PGloveCost
+
+class Adagrad : public IOptimizer {              // J/opt/grad/Adagrad.java + J/opt/Optimizer.java
+public:
+    Adagrad(const CoOccurrenceMatrix &m, const Configuration &config, CostFunction cf, void (*progress)(int, double, double) = nullptr)
+        : coCount_(m.coOccurrenceCount()), vocab_(m.vocabSize()), dim_(config.dim), maxIter_(config.opt.maxiter),
+          tolerance_(config.opt.tolerance), progress_(progress) {
+        ge_glove_cfg cfg;
+        ge_glove_cfg_default(&cfg);
+        cfg.vocab_size = vocab_; cfg.dim = dim_; cfg.nnz = coCount_;
+        cfg.cost = cf == CostFunction::GLOVE ? GE_COST_GLOVE : GE_COST_PGLOVE;
+        cfg.xmax = m.max();
+        cfg.threads = config.getThreads();
+        // Main seeds from the wall clock (Configuration.setThreadLocalRandom(), J/Main.java:62); `device.seed` pins it
+        cfg.seed = config.device.has_seed ? config.device.seed : (long long)(std::time(nullptr)) * 1000LL;
+        cfg.mode = config.device.mode == "deterministic" ? GE_MODE_DETERMINISTIC : GE_MODE_HOGWILD;
+        cfg.shuffle = config.device.shuffle == "java" ? GE_SHUFFLE_JAVA : config.device.shuffle == "none" ? GE_SHUFFLE_NONE : GE_SHUFFLE_DEVICE;
+        cfg.hot_columns = config.device.hot == "none" ? GE_HOT_NONE : config.device.hot == "all" ? GE_HOT_ALL : GE_HOT_AUTO;
+        cfg.workers = config.device.workers;
+        cfg.device = config.device.id;
+        ge_glove *h = nullptr;
+        check(ge_glove_create(&cfg, m.dataI(), m.dataJ(), m.dataX(), &h));
+        h_.reset(h);
+    }
+    std::string getName() const override { return "Adagrad"; }
+    Optimum optimize() override {                 // Optimizer.optimize, J/opt/Optimizer.java:66-120
+        Optimum opt;
+        double finalCost = 0, prevCost = 0;
+        for (int iteration = 0; iteration < maxIter_; ++iteration) {
+            double localCost = 0;
+            check(ge_glove_epoch(h_.get(), iteration, &localCost));
+            localCost = localCost / coCount_;
+            opt.costHistory.push_back(localCost);
+            const double iterDiff = std::fabs(prevCost - localCost);
+            if (progress_) progress_(iteration, localCost, iterDiff);
+            prevCost = localCost;
+            if (iterDiff <= tolerance_) { finalCost = localCost; break; }
+        }
+        opt.result = extractResult();
+        opt.finalCost = finalCost;
+        return opt;
+    }
+    std::vector<double> extractResult() override {
+        std::vector<double> out((size_t)vocab_ * (size_t)dim_);
+        check(ge_glove_extract_f64(h_.get(), out.data()));
+        return out;
+    }
+private:
+    struct Del { void operator()(ge_glove *g) const { ge_glove_destroy(g); } };
+    std::unique_ptr<ge_glove, Del> h_;
+    int coCount_, vocab_, dim_, maxIter_;
+    double tolerance_;
+    void (*progress_)(int, double, double);
+};
+
+// Main.createOptimizer (J/Main.java:107-131)
+inline std::unique_ptr<IOptimizer> createOptimizer(const Configuration &config, const CoOccurrenceMatrix &m,
+                                                   void (*progress)(int, double, double) = nullptr) {
+    std::string method = config.method; for (auto &ch : method) ch = (char)std::toupper((unsigned char)ch);
+    CostFunction cf;
+    if (method == "GLOVE") cf = CostFunction::GLOVE; else if (method == "PGLOVE") cf = CostFunction::PGLOVE;
+    else throw std::invalid_argument("Invalid cost function");
+    std::string om = config.opt.method; for (auto &ch : om) ch = (char)std::toupper((unsigned char)ch);
+    if (om == "ADAGRAD") return std::unique_ptr<IOptimizer>(new Adagrad(m, config, cf, progress));
+    if (om == "ADAM" || om == "AMSGRAD") throw std::invalid_argument("optimization method " + config.opt.method + " is not available in the device library yet (adagrad only)");
+    throw std::invalid_argument("Invalid optimization method");
+}
+
+// ------------------------------------------------------------------------------------------------
+// EmbeddingTextWriter (J/util/write/EmbeddingTextWriter.java)
+// ------------------------------------------------------------------------------------------------
+class EmbeddingTextWriter {
+public:
+    EmbeddingTextWriter(const std::string &fileName, const Configuration &config)
+        : vectors_(fileName + ".vectors.tsv"), dict_(fileName + ".dict.tsv"), config_(config) {
+        write_[URI] = config.output.has_uri; write_[BLANK] = config.output.has_blank; write_[LITERAL] = config.output.has_literal;
+    }
+    // returns the number of vectors written
+    long long write(const Optimum &optimum, const CoOccurrenceMatrix &m, const std::string &outputFolder) {
+        std::filesystem::create_directories(outputFolder);      // Files.createDirectories(outputFolder)
+        std::ofstream dict(outputFolder + "/" + dict_), vect(outputFolder + "/" + vectors_);
+        if (!dict || !vect) throw std::runtime_error("cannot open output files in " + outputFolder);
+        for (auto &l : config_.banner()) { dict << "# " << l << "\n"; vect << "# " << l << "\n"; }
+        dict << "key\ttype\n";
+        const int V = m.vocabSize(), D = config_.dim;
+        static const char *names[3] = {"URI", "BLANK", "LITERAL"};
+        long long written = 0;
+        std::string row;
+        for (int i = 0; i < V; ++i) {
+            const int8_t type = m.getType(i);
+            if (!write_[type]) continue;
+            const std::string key = m.getKey(i);
+            const std::vector<std::string> &pre = type == URI ? config_.output.uri : type == BLANK ? config_.output.blank : config_.output.literal;
+            if (!pre.empty()) {
+                bool any = false;
+                for (auto &p : pre) if (key.compare(0, p.size(), p) == 0) { any = true; break; }
+                if (!any) continue;
+            }
+            row.clear();
+            for (int d = 0; d < D; ++d) { if (d) row.push_back('\t'); row += java_format_11_6E(optimum.result[(size_t)d + (size_t)i * D]); }
+            vect << row << "\n";
+            std::string clean;
+            for (char ch : key) if (ch != '\n' && ch != '\r' && ch != '\t') clean.push_back(ch);
+            dict << clean << "\t" << names[type] << "\n";
+            ++written;
+        }
+        return written;
+    }
+    const std::string &vectorsFile() const { return vectors_; }
+    const std::string &dictFile() const { return dict_; }
+private:
+    std::string vectors_, dict_;
+    const Configuration &config_;
+    bool write_[3];
+};
+
+}  // namespace ge_host

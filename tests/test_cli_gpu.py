@@ -1,0 +1,78 @@
+"""End to end: `geglove -c tests/golden/tiny.config.yml` (the reference's CLI shape, J/Main.java:133-160)
+writes out/<name>.vectors.tsv + .dict.tsv in the reference's format; the numbers equal the oracle pipeline."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle as O
+from geglove import synth
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(REPO, "graph-embeddings_amd", "bin", "geglove")
+
+
+def _graph_from_host():
+    L = C.CDLL(os.path.join(REPO, "graph-embeddings_amd", "lib", "libgehost.so"))
+    L.geh_graph_summary.restype = C.c_char_p
+    out = L.geh_graph_summary(os.path.join(REPO, "tests/golden/tiny.config.yml").encode(),
+                              os.path.join(REPO, "tests/golden/tiny.nt").encode()).decode().splitlines()
+    V = int(re.match(r"V=(\d+)", out[1]).group(1))
+    src, dst, w, keys, types = [], [], [], [], []
+    for line in out[2:]:
+        v, t, key, o, _ = line.split("\t")
+        keys.append(key); types.append(int(t))
+        for m in re.finditer(r"(\d+)\(([^)]+)\)", o):
+            src.append(int(v)); dst.append(int(m.group(1))); w.append(float(m.group(2)))
+    o_csr, i_csr = synth.edges_to_csr(V, np.array(src), np.array(dst), np.array(w, np.float32))
+    return dict(V=V, out=o_csr, inn=i_csr), keys, types
+
+
+def test_cli_end_to_end(gpu, tmp_path):
+    assert os.path.exists(EXE), "host CLI not built"
+    cwd = tmp_path
+    os.makedirs(cwd / "tests" / "golden")
+    for f in ("tiny.config.yml", "tiny.nt"):
+        (cwd / "tests" / "golden" / f).write_bytes(open(os.path.join(REPO, "tests", "golden", f), "rb").read())
+    r = subprocess.run([EXE, "-c", "tests/golden/tiny.config.yml"], cwd=cwd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "Writing files with prefix: tiny_pglove_partial_directed_0.1_0.001_adagrad_pca_8" in r.stdout
+    name = "tiny_pglove_partial_directed_0.1_0.001_adagrad_pca_8"
+    vec = (cwd / "out" / (name + ".vectors.tsv")).read_text().splitlines()
+    dic = (cwd / "out" / (name + ".dict.tsv")).read_text().splitlines()
+    # header = writeConfig(); SimilarityGroup.toString() contains a newline, so its second line has no '#'
+    # (EmbeddingTextWriter.java:66-68 writes "# " + s.toString() verbatim) -- reproduced as is
+    k = dic.index("key\ttype")
+    hd, rows = dic[:k], dic[k + 1:]
+    hv, body_v = vec[:k], vec[k:]
+    assert hv == hd and hv[0] == "# Starting the embedding creation process with following settings:"
+    assert "# BCA Alpha: 0.1" in hv and "# pglove Maximum Iterations: 3" in hv
+    assert " method:jarowinkler, threshold: 0.95" in hv
+    assert rows == ["http://ex.org/authors/a1\tURI", "http://ex.org/authors/a2\tURI", "http://ex.org/authors/a3\tURI"]   # prefix filter
+    assert len(body_v) == len(rows)
+    assert all(re.fullmatch(r"-?\d\.\d{6}E[+-]\d{2}", x) for l in body_v for x in l.split("\t"))      # %11.6E
+    # numbers: oracle pipeline on the same graph, same seed, threads 1, tolerance/maxiter of the config
+    g, keys, types = _graph_from_host()
+    coo = O.bca_build(g["V"], g["out"], g["inn"], 0.1, 1e-3, True, O.NORM_NONE)
+    m = O.Glove(g["V"], 8, coo["I"], coo["J"], coo["X"], coo["max"], O.COST_PGLOVE, seed=42, threads=1)
+    m.optimize(3, 1e-4)
+    ref = m.extract()
+    want = [i for i, k in enumerate(keys) if k.startswith("http://ex.org/authors/")]
+    got = np.array([[float(x) for x in l.split("\t")] for l in body_v])
+    np.testing.assert_allclose(got, ref[want], rtol=5e-7, atol=0)
+    for l, i in zip(body_v, want):
+        assert l.split("\t") == [O.format_11_6E(v) for v in ref[i]]          # byte-identical text
+
+
+def test_cli_error_paths(gpu, tmp_path):
+    r = subprocess.run([EXE, "-c", "missing.yml"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "Cannot find configuration file + missing.yml" in r.stderr
+    (tmp_path / "bad.yml").write_text("graph: g.nt\nmethod: glove\n")
+    r = subprocess.run([EXE, "-c", "bad.yml"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "Invalid configuration: No dimension specified" in r.stderr
+    r = subprocess.run([EXE, "-c"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "No configuration file specified, exiting..." in r.stderr
