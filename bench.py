@@ -4,7 +4,7 @@
 A "step" is one pass of the hot path (ge_glove_epoch: the AdaGrad pair-update kernel over every
 nonzero this rank owns) over the synthetic co-occurrence matrix; inputs are resident in HBM before
 the timed region.  Weak scaling: every GPU owns ROWS_PER_GPU focus rows and ~NNZ_PER_GPU nonzeros,
-the context factors are replicated and reconciled by a sum-of-deltas all-reduce (RCCL) per step,
+the context factors are replicated and reconciled by an all-reduce of the per-rank deltas (RCCL) per step,
 so at 8 GPUs the job is BASELINE config C4 (5 M vertices / 1 B nonzeros / dim 200).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (HIP-event
@@ -111,11 +111,14 @@ def main():
 
     sync = None
     if world > 1:
-        tensors = []
-        for name in ("context", "gsq_context", "cbias", "gsq_cbias"):
+        dev = torch.device("cuda", local_rank)
+
+        def wrap(name):
             ptr, cnt = opt.device_ptr(name)
-            tensors.append(torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=torch.device("cuda", local_rank)))
-        sync = parallel.ContextSync(tensors)
+            return torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=dev)
+
+        sync = parallel.ContextSync(params=[(wrap("context"), D), (wrap("cbias"), 1)],
+                                    accums=[wrap("gsq_context"), wrap("gsq_cbias")])
 
     def step(it):
         c = opt.epoch(it)
@@ -169,7 +172,7 @@ def main():
                                    "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, AdaGrad Hogwild, per-epoch device shuffle"
                                    % (world, "s" if world > 1 else "", V, n_local, D, args.method),
                        "vocab": V, "nnz_per_gpu": n_local, "dim": D, "cost": args.method,
-                       "parallelism": "rows sharded x%d, context replicated + sum-of-deltas all-reduce every %d step(s)"
+                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce (mean over contributing ranks) every %d step(s)"
                                       % (world, args.sync_every) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "traffic": None,

@@ -3,7 +3,8 @@
 GPU g owns focus rows / fBias / their gradSq for a contiguous row block and every nonzero whose
 i falls in it (BookmarkColoring output is already grouped by i).  The context factors (context,
 cBias, gradSqContext, gradSqCBias) are replicated, updated locally Hogwild, and reconciled by a
-periodic SUM-OF-DELTAS all-reduce over RCCL/xGMI:   new = old + sum_g (local_g - old).
+periodic all-reduce of the per-rank deltas over RCCL/xGMI (ContextSync below: mean over the ranks
+that touched a row for the parameters, sum for the AdaGrad accumulators).
 
 The reference has no multi-device semantics (single JVM); parity of this path is statistical
 (cost history vs. a 1-GPU run), stated in DESIGN.md.
@@ -40,29 +41,49 @@ class DeviceArray:
 
 
 class ContextSync:
-    """Sum-of-deltas all-reduce of the replicated context-side tables.
+    """Reconciles the replicated context-side tables after every rank has run its local pass.
 
-    tensors: list of torch tensors (one per replicated table) that the local trainer updates in
-    place.  After every rank has finished its local pass call sync(): each table becomes
-    old + sum over ranks of (local - old), computed as  allreduce_sum(local) - (world-1)*old
-    so that only ONE collective buffer per table is in flight and no delta temp is needed.
+    params:  [(tensor, row_len)] tables that hold PARAMETERS (context [V*D] with row_len=D, cBias [V] with
+             row_len=1).  Merge rule per row:  new = old + (sum over ranks of delta) / (number of ranks whose
+             delta for that row is non-zero).  A row that only one rank touched gets its full update; a hub
+             row that every rank moved gets the mean of the moves.  (A plain sum of whole-pass deltas
+             diverges: each rank alone already moves a hub row most of the way -- measured in DESIGN.md.)
+    accums:  [tensor] AdaGrad accumulators (gradSqContext, gradSqCBias): plain sum of deltas -- squared
+             gradients add up no matter which rank saw them.
+    Works on CPU tensors with gloo (tests) and on device memory with nccl = RCCL over xGMI (bench.py).
     """
 
-    def __init__(self, tensors, group=None):
+    def __init__(self, params, accums, group=None):
+        import torch
         import torch.distributed as dist
-        self.dist = dist
-        self.group = group
+        self.torch, self.dist, self.group = torch, dist, group
         self.world = dist.get_world_size(group)
-        self.tensors = list(tensors)
-        self.old = [t.clone() for t in self.tensors]
+        self.params = [(t, int(n)) for t, n in params]
+        self.accums = list(accums)
+        self.old_p = [t.clone() for t, _ in self.params]
+        self.old_a = [t.clone() for t in self.accums]
 
     def sync(self):
         if self.world == 1:
             return
-        handles = [self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-                   for t in self.tensors]
-        for h in handles:
-            h.wait()
-        for t, o in zip(self.tensors, self.old):
-            t.sub_(o, alpha=float(self.world - 1))
+        torch, dist = self.torch, self.dist
+        work = []
+        counts = []
+        for (t, n), o in zip(self.params, self.old_p):
+            t.sub_(o)                                                   # t now holds this rank's delta
+            cnt = t.view(-1, n).ne(0).any(dim=1).to(torch.float32)
+            counts.append(cnt)
+            work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            work.append(dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for t, o in zip(self.accums, self.old_a):
+            t.sub_(o)
+            work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in work:
+            w.wait()
+        for (t, n), o, cnt in zip(self.params, self.old_p, counts):
+            t.view(-1, n).div_(cnt.clamp_(min=1.0).unsqueeze(1))
+            t.add_(o)
+            o.copy_(t)
+        for t, o in zip(self.accums, self.old_a):
+            t.add_(o)
             o.copy_(t)

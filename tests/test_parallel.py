@@ -1,0 +1,94 @@
+"""Multi-GPU path on CPU: world_size-2 gloo processes drive geglove.parallel (row sharding + ContextSync)
+with the oracle standing in for the per-rank device pass (the N>1 host logic is what is under test here;
+the device pass itself is covered by the GPU parity tests)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle as O
+from geglove import parallel, synth
+
+CTX = ("context", "cbias", "gsq_context", "gsq_cbias")
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rank_main(rank, world, port, V, N, D, epochs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
+    rows = parallel.shard_rows(V, world, rank)
+    si, sj, sx = parallel.shard_nonzeros(I, J, X, rows)
+    base = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)       # same init on every rank
+    st = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in base.state().items()}
+    view = {k: t.numpy() for k, t in st.items()}                                 # oracle updates torch memory in place
+    sync = parallel.ContextSync(params=[(st["context"].view(-1), D), (st["cbias"], 1)],
+                                accums=[st["gsq_context"].view(-1), st["gsq_cbias"]])
+    rng = np.random.default_rng(100 + rank)
+    costs = []
+    for _ in range(epochs):
+        p = rng.permutation(len(si))
+        c = float(O.adagrad_job(D, si[p], sj[p], sx[p], xmax, O.COST_GLOVE, view))
+        sync.sync()
+        t = torch.tensor([c], dtype=torch.float64); dist.all_reduce(t)
+        costs.append(float(t.item()) / len(I))
+    digest = torch.tensor([float(st[k].double().sum()) for k in CTX], dtype=torch.float64)
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    if rank == 0:
+        q.put((costs, [g.tolist() for g in gathered], rows))
+    dist.destroy_process_group()
+
+
+def _run(world, V=1500, N=40000, D=8, epochs=4):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, V, N, D, epochs, q)) for r in range(world)]
+    for p in procs: p.start()
+    out = q.get(timeout=300)
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    return out
+
+
+def test_shard_rows_and_nonzeros_partition_the_matrix():
+    V = 103
+    blocks = [parallel.shard_rows(V, 8, r) for r in range(8)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == V
+    assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+    assert max(e - b for b, e in blocks) - min(e - b for b, e in blocks) <= 1
+    I, J, X, _ = synth.synthetic_coo(V, 2000, seed=1)
+    parts = [parallel.shard_nonzeros(I, J, X, b) for b in blocks]
+    assert sum(len(p[0]) for p in parts) == len(I)
+    np.testing.assert_array_equal(np.concatenate([p[0] for p in parts]), I)      # BCA output is grouped by row
+    for (b, e), p in zip(blocks, parts):
+        assert np.all((p[0] >= b) & (p[0] < e))
+
+
+def test_two_ranks_stay_replicated_and_track_the_single_process_run():
+    costs, digests, _ = _run(2)
+    assert digests[0] == digests[1]                                # context side identical on both ranks after sync
+    I, J, X, xmax = synth.synthetic_coo(1500, 40000, seed=13)
+    ora = O.Glove(1500, 8, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
+    ref = [ora.epoch() for _ in range(4)]
+    assert np.all(np.isfinite(costs)) and costs[-1] < costs[0]
+    np.testing.assert_allclose(costs, ref, rtol=0.10)              # statistical parity of the sharded run
+
+
+def test_context_sync_merge_rule_single_process_math():
+    """world_size 1 group inside this process: the rule itself on hand-made deltas (2 fake ranks folded by hand)."""
+    old = np.array([[1., 1.], [2., 2.], [3., 3.]], np.float32)
+    d0 = np.array([[.5, 0.], [0., 0.], [1., 1.]], np.float32)      # rank 0 touched rows 0, 2
+    d1 = np.array([[0., 0.], [0., 0.], [3., -1.]], np.float32)     # rank 1 touched row 2
+    cnt = ((np.abs(d0).max(1) > 0).astype(np.float32) + (np.abs(d1).max(1) > 0))
+    exp = old + (d0 + d1) / np.maximum(cnt, 1)[:, None]
+    np.testing.assert_array_equal(exp, [[1.5, 1.], [2., 2.], [5., 3.]])
