@@ -35,6 +35,13 @@ struct GloveParams {
     const int32_t *perm;
     const double *L;       // Hogwild: per-nonzero log term  (k_cost_terms)
     const float *W;        // Hogwild: per-nonzero weight
+    const int32_t *bA, *bB;   // Hogwild, blocked order: resident / streamed row id per re-ordered position
+    int64_t n_chunks;         // chunks of RUN_CHUNK nonzeros per epoch
+    int64_t n_hchunks;        // blocked order: the first n_hchunks chunks are hub columns (column-major)
+    int32_t blocked;          // 1: chunk c = positions [128c, 128c+128) of the re-ordered arrays
+    int32_t hot_enabled;      // blocked order: hub chunks publish deltas with atomics
+    int32_t flush_every;      // a hub run publishes its delta at least every this many nonzeros (general order)
+    const int32_t *chunk_flush;   // blocked order: the same limit per hub chunk (n_hchunks entries)
     double *cost_out;      // Hogwild: one double accumulator
     unsigned long long *queue;   // Hogwild: next chunk to hand out (zeroed before every launch)
     double xmax;
@@ -83,7 +90,7 @@ __global__ void k_cost_terms(const float *X, int64_t n, int kind, double xmax, d
 // ---- epoch order ----------------------------------------------------------------------
 // Keyed bijection of [0, 2^b) (odd multiply, xor-shift, add key: each step invertible),
 // cycle-walked into [0, N).  2^b < 2N so the expected number of rounds is < 2.
-__device__ __forceinline__ uint32_t bij_round(uint32_t x, const GloveParams &p) {
+__host__ __device__ __forceinline__ uint32_t bij_round(uint32_t x, const GloveParams &p) {
     const uint32_t m = p.bij_mask, s = p.bij_shift;
     x = (x + p.bij_key[0]) & m;  x = (x * 0x9E3779B1u) & m;  x ^= x >> s;
     x = (x + p.bij_key[1]) & m;  x = (x * 0x85EBCA6Bu) & m;  x ^= x >> s;
@@ -265,7 +272,7 @@ constexpr int RUN_CHUNK = 128;            // nonzeros per worker chunk (2 per la
 constexpr int KEY_PAD = 0x7FFFFFFF;       // sorts last; marks the unused tail of the last chunk
 
 template <int VW, int NCH>
-__global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_begin, int64_t k_end, int32_t V, int32_t n_workers) {
+__global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_workers) {
     using VT = typename Vec<VW>::T;
     const int lane = threadIdx.x & 63;
     const int32_t D = p.D;
@@ -273,35 +280,50 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
     const float lr = p.lr;
     const int wave = rfl((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (wave >= n_workers) return;          // workers pull chunks of the epoch order from one queue
-    const int64_t n = k_end - k_begin;
-    const int64_t n_chunks = (n + RUN_CHUNK - 1) / RUN_CHUNK;
+    const int64_t n_chunks = p.n_chunks;
     __shared__ float s_tr[4][2][NCH * 64 * VW];       // per-wave strip for the atomic flush (no block barrier)
-    const uint32_t bias_bytes = (uint32_t)((uint64_t)V * 4u > 0xFFFFFFFFull ? 0xFFFFFFFFull : (uint64_t)V * 4u);
-    // the focus-side pointers are rebased by the owned row range; bias tables are addressed by global row id
-    const __amdgpu_buffer_rsrc_t rs_cb = make_rsrc(p.cbias, bias_bytes), rs_gcb = make_rsrc(p.gscb, bias_bytes);
     double cost_acc = 0.0;
+    bool inr[NCH];                          // lane holds real elements of a row (D % VW == 0)
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) inr[q] = (lane + q * 64) * VW < D;
 
     for (;;) {
         unsigned long long ticket = 0;
         if (lane == 0) ticket = atomicAdd(p.queue, 1ull);
-        const int64_t chunk = ((int64_t)(unsigned)rfl((int)(ticket >> 32)) << 32) | (unsigned)rfl((int)(ticket & 0xFFFFFFFFull));
-        if (chunk >= n_chunks) break;
+        const int64_t tk = ((int64_t)(unsigned)rfl((int)(ticket >> 32)) << 32) | (unsigned)rfl((int)(ticket & 0xFFFFFFFFull));
+        if (tk >= n_chunks) break;
+
         // ---- stage: two nonzeros per lane ------------------------------------------------------
-        int32_t key[2], slot[2], ii[2];
+        // key = id of the RESIDENT row (sorted on, kept in registers across a run), oth = id of the
+        // STREAMED row.  Blocked order: chunk c of the re-ordered arrays; chunks [0, n_hchunks) are the
+        // hub columns in column-major order (resident = context row, hot), the others are the rest of
+        // the matrix in row-major order (resident = focus row).  General order (Java permutation /
+        // matrix order): the resident side is always the context row, hub columns are keyed ~j.
+        int32_t key[2], slot[2], oth[2];
         float ww[2];
         double ll[2];
-        const int64_t base = k_begin + chunk * RUN_CHUNK;
+        int64_t chunk = tk;
+        bool res_is_ctx = true;
+        if (p.blocked) {
+            uint32_t x = (uint32_t)tk;
+            if (p.order_mode == ORDER_BIJECTION) { do { x = bij_round(x, p); } while ((int64_t)x >= n_chunks); }
+            chunk = rfl((int)x);
+            res_is_ctx = chunk < p.n_hchunks;
+        }
+        const int flush_every = (p.blocked && res_is_ctx) ? p.chunk_flush[chunk] : p.flush_every;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int64_t k = base + q * 64 + lane;
-            key[q] = KEY_PAD; ii[q] = 0; ww[q] = 0.0f; ll[q] = 0.0;
+            const int64_t k = chunk * RUN_CHUNK + q * 64 + lane;
+            key[q] = KEY_PAD; oth[q] = 0; ww[q] = 0.0f; ll[q] = 0.0;
             slot[q] = q * 64 + lane;
-            if (k < k_end) {
+            if (p.blocked) {
+                key[q] = p.bA[k]; oth[q] = p.bB[k]; ww[q] = p.W[k]; ll[q] = p.L[k];
+            } else if (k < p.N) {
                 const int64_t idx = map_index(p, k);
-                key[q] = p.J[idx]; ii[q] = p.I[idx]; ww[q] = p.W[idx]; ll[q] = p.L[idx];
+                key[q] = p.J[idx]; oth[q] = p.I[idx]; ww[q] = p.W[idx]; ll[q] = p.L[idx];
             }
         }
-        const int n_valid = rfl((int)((k_end - base) < RUN_CHUNK ? (k_end - base) : RUN_CHUNK));
+        const int n_valid = rfl(__popcll(__ballot(key[0] != KEY_PAD)) + __popcll(__ballot(key[1] != KEY_PAD)));
 
         // ---- bitonic sort of (key, slot) over positions pos = q*64 + lane ---------------------
 #pragma unroll
@@ -310,8 +332,8 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
             for (int j2 = k2 >> 1; j2 >= 1; j2 >>= 1) {
                 if (j2 == 64) {
                     if (key[0] > key[1] || (key[0] == key[1] && slot[0] > slot[1])) {   // k2 == 128: ascending everywhere
-                        const int32_t tk = key[0], ts = slot[0];
-                        key[0] = key[1]; slot[0] = slot[1]; key[1] = tk; slot[1] = ts;
+                        const int32_t tkk = key[0], ts = slot[0];
+                        key[0] = key[1]; slot[0] = slot[1]; key[1] = tkk; slot[1] = ts;
                     }
                 } else {
 #pragma unroll
@@ -321,7 +343,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
                         const int32_t ps = __shfl_xor(slot[q], j2, 64);
                         const bool asc = (pos & k2) == 0;
                         const bool lower = (lane & j2) == 0;
-                        // total order (key, slot): the walk order is the STABLE sort of the chunk by column
+                        // total order (key, slot): the walk order is the STABLE sort of the chunk by resident row
                         const bool p_less = pk < key[q] || (pk == key[q] && ps < slot[q]);
                         const bool take = (asc == lower) ? p_less : !p_less;
                         if (take) { key[q] = pk; slot[q] = ps; }
@@ -330,30 +352,28 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
             }
         }
 
+        // ---- table roles for this chunk (wave-uniform) ------------------------------------------
+        // The update is symmetric in the two sides: A = resident, B = streamed.
+        float *const A_rows = res_is_ctx ? p.context : p.focus, *const A_gs = res_is_ctx ? p.gsc : p.gsf;
+        float *const A_bias = res_is_ctx ? p.cbias : p.fbias,  *const A_gsb = res_is_ctx ? p.gscb : p.gsfb;
+        float *const B_rows = res_is_ctx ? p.focus : p.context, *const B_gs = res_is_ctx ? p.gsf : p.gsc;
+        float *const B_bias = res_is_ctx ? p.fbias : p.cbias,  *const B_gsb = res_is_ctx ? p.gsfb : p.gscb;
+
         // ---- sequential walk ---------------------------------------------------------------------
-        // Software pipeline: while nonzero `pos` is computed, the focus rows of pos+1 and (when the
-        // column changes there) its context rows are already in flight.  They are requested BEFORE
+        // Software pipeline: while nonzero `pos` is computed, the streamed rows of pos+1 and (when the
+        // resident row changes there) its resident rows are already in flight.  They are requested BEFORE
         // this nonzero's stores, so waiting for them never waits for a store to retire.
-        int32_t cur_key = KEY_PAD;
-        VT c[NCH], gc[NCH], c0[NCH], gc0[NCH];
-        float cb = 0.0f, gcb = 0.0f;
-        __amdgpu_buffer_rsrc_t rs_c = rs_cb, rs_gc = rs_cb;
-        bool inr[NCH];                      // lane holds real elements of the row (D % VW == 0)
-#pragma unroll
-        for (int q = 0; q < NCH; ++q) inr[q] = (lane + q * 64) * VW < D;
+        int32_t cur_id = 0; bool cur_hot = false;
+        VT a[NCH], ga[NCH], a0[NCH], ga0[NCH];
+        float ab = 0.0f, gab = 0.0f;
+        __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A_rows, 0), rs_ga = rs_a;
 
         auto close_run = [&]() {
-            const bool hot = cur_key < 0;
-            const int32_t bv = hot ? ~cur_key : cur_key;
-            if (!hot) {
+            if (!cur_hot) {
 #pragma unroll
                 for (int q = 0; q < NCH; ++q) {
-                    buf_store<VW>(c[q], rs_c, (lane + q * 64) * VW * 4);
-                    buf_store<VW>(gc[q], rs_gc, (lane + q * 64) * VW * 4);
-                }
-                if (lane == 0) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cb), rs_cb, bv * 4, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gcb), rs_gcb, bv * 4, 0, AUX_SC1);
+                    buf_store<VW>(a[q], rs_a, (lane + q * 64) * VW * 4);
+                    buf_store<VW>(ga[q], rs_ga, (lane + q * 64) * VW * 4);
                 }
             } else {
                 // Publish the run's delta with float atomics.  Lane L holds elements [VW*L, VW*L+VW);
@@ -365,8 +385,8 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
                     VT dc, dg;
 #pragma unroll
                     for (int t = 0; t < VW; ++t) {
-                        comp<VW>(dc, t) = comp<VW>(c[q], t) - comp<VW>(c0[q], t);
-                        comp<VW>(dg, t) = comp<VW>(gc[q], t) - comp<VW>(gc0[q], t);
+                        comp<VW>(dc, t) = comp<VW>(a[q], t) - comp<VW>(a0[q], t);
+                        comp<VW>(dg, t) = comp<VW>(ga[q], t) - comp<VW>(ga0[q], t);
                     }
                     *reinterpret_cast<VT *>(tr_c + (lane + q * 64) * VW) = dc;
                     *reinterpret_cast<VT *>(tr_g + (lane + q * 64) * VW) = dg;
@@ -377,93 +397,88 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
 #pragma unroll
                 for (int k = 0; k < NCH * VW; ++k) {
                     const int e = lane + k * 64;          // element index; past D the buffer check drops it
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_c[e], rs_c, e * 4, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_g[e], rs_gc, e * 4, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_c[e], rs_a, e * 4, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_g[e], rs_ga, e * 4, 0, 0);
                 }
                 __builtin_amdgcn_wave_barrier();
-                // The bias takes AdaGrad steps WITHOUT a learning rate (Adagrad.java:88-89): one run
-                // alone already moves it most of the way, so concurrent runs must not add up.  The
-                // scalars are merged last-writer-wins (what the Java race does), written through (sc1)
-                // so that the other XCDs' coherent loads see them.
-                if (lane == 0) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cb), rs_cb, bv * 4, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gcb), rs_gcb, bv * 4, 0, AUX_SC1);
-                }
+            }
+            // The bias takes AdaGrad steps WITHOUT a learning rate (Adagrad.java:88-89): one run alone
+            // already moves it most of the way, so concurrent hub runs must not add up.  The scalars are
+            // merged last-writer-wins (what the Java race does), written through (sc1) like every table.
+            if (lane == 0) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ab), make_rsrc(A_bias + cur_id, 4), 0, 0, AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gab), make_rsrc(A_gsb + cur_id, 4), 0, 0, AUX_SC1);
             }
         };
 
         // decoded next nonzero + its prefetched rows
-        int32_t n_bu = 0, n_key = KEY_PAD; float n_w = 0.0f; double n_l = 0.0;
-        VT nf[NCH], ngf[NCH]; float n_fb = 0.0f, n_gfb = 0.0f;
-        VT cN[NCH], gcN[NCH]; float cbN = 0.0f, gcbN = 0.0f;
-        __amdgpu_buffer_rsrc_t rsN_c = rs_cb, rsN_gc = rs_cb;
+        int32_t n_oth = 0, n_key = KEY_PAD; float n_w = 0.0f; double n_l = 0.0;
+        VT nb[NCH], ngb[NCH]; float n_bb = 0.0f, n_gbb = 0.0f;
+        VT aN[NCH], gaN[NCH]; float abN = 0.0f, gabN = 0.0f;
+        __amdgpu_buffer_rsrc_t rsN_a = rs_a, rsN_ga = rs_a;
         auto decode = [&](int pos) {
             const int q = pos >> 6, ln = pos & 63;
             n_key = __builtin_amdgcn_readlane(q ? key[1] : key[0], ln);
             const int sl = __builtin_amdgcn_readlane(q ? slot[1] : slot[0], ln);
             const int sq = sl >> 6, sln = sl & 63;
-            n_bu = __builtin_amdgcn_readlane(sq ? ii[1] : ii[0], sln);
+            n_oth = __builtin_amdgcn_readlane(sq ? oth[1] : oth[0], sln);
             n_w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sq ? ww[1] : ww[0]), sln));
             const long long lb = __builtin_bit_cast(long long, sq ? ll[1] : ll[0]);
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(lb & 0xFFFFFFFFll), sln);
             const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(lb >> 32), sln);
             n_l = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
         };
-        auto request_focus = [&]() {
-            const __amdgpu_buffer_rsrc_t rf = make_rsrc(p.focus + (int64_t)n_bu * D, row_bytes);
-            const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.gsf + (int64_t)n_bu * D, row_bytes);
+        auto request_streamed = [&]() {
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(B_rows + (int64_t)n_oth * D, row_bytes);
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)n_oth * D, row_bytes);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
-                nf[q]  = buf_load<VW, AUX_SC1>(rf, (lane + q * 64) * VW * 4);
-                ngf[q] = buf_load<VW, AUX_SC1>(rg, (lane + q * 64) * VW * 4);
+                nb[q]  = buf_load<VW, AUX_SC1>(rb, (lane + q * 64) * VW * 4);
+                ngb[q] = buf_load<VW, AUX_SC1>(rg, (lane + q * 64) * VW * 4);
             }
-            n_fb  = buf_load_f32(make_rsrc(p.fbias + n_bu, 4), 0, true);
-            n_gfb = buf_load_f32(make_rsrc(p.gsfb + n_bu, 4), 0, true);
+            n_bb  = buf_load_f32(make_rsrc(B_bias + n_oth, 4), 0, true);
+            n_gbb = buf_load_f32(make_rsrc(B_gsb + n_oth, 4), 0, true);
         };
-        auto request_context = [&]() {
-            const bool hot = n_key < 0;
-            const int32_t bv = hot ? ~n_key : n_key;
-            rsN_c = make_rsrc(p.context + (int64_t)bv * D, row_bytes);
-            rsN_gc = make_rsrc(p.gsc + (int64_t)bv * D, row_bytes);
-            if (hot) {
+        auto request_resident = [&]() {
+            const int32_t id = n_key < 0 ? ~n_key : n_key;
+            rsN_a = make_rsrc(A_rows + (int64_t)id * D, row_bytes);
+            rsN_ga = make_rsrc(A_gs + (int64_t)id * D, row_bytes);
 #pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    cN[q]  = buf_load<VW, AUX_SC1>(rsN_c, (lane + q * 64) * VW * 4);
-                    gcN[q] = buf_load<VW, AUX_SC1>(rsN_gc, (lane + q * 64) * VW * 4);
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    cN[q]  = buf_load<VW, AUX_SC1>(rsN_c, (lane + q * 64) * VW * 4);
-                    gcN[q] = buf_load<VW, AUX_SC1>(rsN_gc, (lane + q * 64) * VW * 4);
-                }
+            for (int q = 0; q < NCH; ++q) {
+                aN[q]  = buf_load<VW, AUX_SC1>(rsN_a, (lane + q * 64) * VW * 4);
+                gaN[q] = buf_load<VW, AUX_SC1>(rsN_ga, (lane + q * 64) * VW * 4);
             }
-            cbN  = buf_load_f32(rs_cb, bv * 4, true);
-            gcbN = buf_load_f32(rs_gcb, bv * 4, true);
+            abN  = buf_load_f32(make_rsrc(A_bias + id, 4), 0, true);
+            gabN = buf_load_f32(make_rsrc(A_gsb + id, 4), 0, true);
         };
 
         bool open_new = true;
-        if (n_valid > 0) { decode(0); request_focus(); request_context(); }
+        int run_len = 0;
+        if (n_valid > 0) { decode(0); request_streamed(); request_resident(); }
         for (int pos = 0; pos < n_valid; ++pos) {
-            const int32_t bu = n_bu, skey = n_key;
+            const int32_t b_id = n_oth, skey = n_key;
             const float w = n_w; const double l = n_l;
-            VT f[NCH], gf[NCH];
+            VT b[NCH], gb[NCH];
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) { f[q] = nf[q]; gf[q] = ngf[q]; }
-            const float fb = n_fb, gfb = n_gfb;
+            for (int q = 0; q < NCH; ++q) { b[q] = nb[q]; gb[q] = ngb[q]; }
+            const float bb = n_bb, gbb = n_gbb;
             if (open_new) {
 #pragma unroll
-                for (int q = 0; q < NCH; ++q) { c[q] = cN[q]; gc[q] = gcN[q]; c0[q] = cN[q]; gc0[q] = gcN[q]; }
-                cb = cbN; gcb = gcbN;
-                cur_key = skey; rs_c = rsN_c; rs_gc = rsN_gc;
+                for (int q = 0; q < NCH; ++q) { a[q] = aN[q]; ga[q] = gaN[q]; a0[q] = aN[q]; ga0[q] = gaN[q]; }
+                ab = abN; gab = gabN;
+                cur_id = skey < 0 ? ~skey : skey;
+                cur_hot = res_is_ctx && (p.blocked ? p.hot_enabled != 0 : skey < 0);
+                rs_a = rsN_a; rs_ga = rsN_ga;
+                run_len = 0;
             }
             const bool last = pos + 1 >= n_valid;
             bool deferred = false, next_new = false;
             if (!last) {
                 decode(pos + 1);
-                if (n_bu != bu) request_focus(); else deferred = true;    // same focus row twice in a row: re-read after the store
-                next_new = n_key != skey;
-                if (next_new) request_context();
+                if (n_oth != b_id) request_streamed(); else deferred = true;   // same streamed row twice in a row: re-read after the store
+                // a long hub run is cut every flush_every nonzeros: publish the delta, re-read what the other workers published
+                next_new = n_key != skey || (cur_hot && run_len + 1 >= flush_every);
+                if (next_new) request_resident();
             }
             // dot product
             float part = 0.0f;
@@ -471,49 +486,51 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int64_t k_b
             for (int q = 0; q < NCH; ++q)
                 if (inr[q]) {
 #pragma unroll
-                    for (int t = 0; t < VW; ++t) part = __builtin_fmaf(comp<VW>(f[q], t), comp<VW>(c[q], t), part);
+                    for (int t = 0; t < VW; ++t) part = __builtin_fmaf(comp<VW>(a[q], t), comp<VW>(b[q], t), part);
                 }
             part = wave_sum(part);
-            const float ic = (float)((double)part + ((double)(fb + cb) - l));
+            const float ic = (float)((double)part + ((double)(ab + bb) - l));
             const float wc = w * ic;
             cost_acc += (0.5 * (double)wc) * (double)ic;
             const float wlr = wc * lr;
-            const __amdgpu_buffer_rsrc_t rf = make_rsrc(p.focus + (int64_t)bu * D, row_bytes);
-            const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.gsf + (int64_t)bu * D, row_bytes);
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(B_rows + (int64_t)b_id * D, row_bytes);
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)b_id * D, row_bytes);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
                 if (inr[q]) {
-                    VT of, ogf;
+                    VT ob, ogb;
 #pragma unroll
                     for (int t = 0; t < VW; ++t) {
-                        const float fv = comp<VW>(f[q], t), cv = comp<VW>(c[q], t);
-                        const float a = comp<VW>(gf[q], t), b = comp<VW>(gc[q], t);
-                        const float grad1 = wc * cv, grad2 = wc * fv;
-                        comp<VW>(of, t)   = __builtin_fmaf(-(wlr * cv), __frsqrt_rn(a), fv);
-                        comp<VW>(ogf, t)  = __builtin_fmaf(grad1, grad1, a);
-                        comp<VW>(c[q], t)  = __builtin_fmaf(-(wlr * fv), __frsqrt_rn(b), cv);
-                        comp<VW>(gc[q], t) = __builtin_fmaf(grad2, grad2, b);
+                        const float av = comp<VW>(a[q], t), bv = comp<VW>(b[q], t);
+                        const float sa = comp<VW>(ga[q], t), sb = comp<VW>(gb[q], t);
+                        const float grad_b = wc * av, grad_a = wc * bv;
+                        comp<VW>(ob, t)    = __builtin_fmaf(-(wlr * av), __frsqrt_rn(sb), bv);
+                        comp<VW>(ogb, t)   = __builtin_fmaf(grad_b, grad_b, sb);
+                        comp<VW>(a[q], t)  = __builtin_fmaf(-(wlr * bv), __frsqrt_rn(sa), av);
+                        comp<VW>(ga[q], t) = __builtin_fmaf(grad_a, grad_a, sa);
                     }
-                    buf_store<VW>(of, rf, (lane + q * 64) * VW * 4);
-                    buf_store<VW>(ogf, rg, (lane + q * 64) * VW * 4);
+                    buf_store<VW>(ob, rb, (lane + q * 64) * VW * 4);
+                    buf_store<VW>(ogb, rg, (lane + q * 64) * VW * 4);
                 }
             }
             const float w2 = wc * wc;
             if (lane == 0) {          // no learning rate on the biases (Adagrad.java:88-89)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, fb - wc * __frsqrt_rn(gfb)), make_rsrc(p.fbias + bu, 4), 0, 0, AUX_SC1);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gfb + w2), make_rsrc(p.gsfb + bu, 4), 0, 0, AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, bb - wc * __frsqrt_rn(gbb)), make_rsrc(B_bias + b_id, 4), 0, 0, AUX_SC1);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gbb + w2), make_rsrc(B_gsb + b_id, 4), 0, 0, AUX_SC1);
             }
-            cb = cb - wc * __frsqrt_rn(gcb);
-            gcb = gcb + w2;
+            ab = ab - wc * __frsqrt_rn(gab);
+            gab = gab + w2;
+            ++run_len;
             if (last || next_new) close_run();
-            if (deferred) request_focus();
+            if (deferred) request_streamed();
             open_new = next_new;
         }
     }
     if (lane == 0 && cost_acc != 0.0) atomicAdd(p.cost_out, cost_acc);
 }
 
-using hogwild_fn = void (*)(GloveParams, int64_t, int64_t, int32_t, int32_t);
+using hogwild_fn = void (*)(GloveParams, int32_t);
+
 
 template <int VW>
 hogwild_fn pick_nch(int nch) {
@@ -562,6 +579,12 @@ struct ge_glove {
     int hw_blocks_per_cu = 4;
     int hw_blocks = 0;
     int hw_workers = 0;
+    bool blocked = false;             // Hogwild + DEVICE shuffle: chunked layout below
+    int64_t n_chunks = 0, n_hchunks = 0;
+    int32_t *dbA = nullptr, *dbB = nullptr, *dchunk_flush = nullptr;
+    int flush_every = RUN_CHUNK;
+    std::vector<int32_t> host_key;    // sort key per (re-ordered) position: what the kernel stages as `key`
+    std::vector<int32_t> host_border; // blocked layout: original nonzero per position (-1 = padding)
     int32_t hot_cols = 0;
     int64_t hot_nnz = 0, hot_threshold = 0;
 };
@@ -591,8 +614,11 @@ void fill_params(const ge_glove *h, GloveParams &p, int32_t iteration) {
     p.cost_kind = h->cfg.cost; p.lr = h->cfg.learning_rate;
     p.order_mode = h->cfg.shuffle == GE_SHUFFLE_JAVA ? ORDER_PERM
                  : h->cfg.shuffle == GE_SHUFFLE_DEVICE ? ORDER_BIJECTION : ORDER_IDENTITY;
+    p.bA = h->dbA; p.bB = h->dbB; p.chunk_flush = h->dchunk_flush; p.n_chunks = h->n_chunks; p.n_hchunks = h->n_hchunks;
+    p.blocked = h->blocked ? 1 : 0; p.hot_enabled = h->cfg.hot_columns != GE_HOT_NONE; p.flush_every = h->flush_every;
+    const int64_t domain = h->blocked ? h->n_chunks : h->cfg.nnz;      // what the keyed bijection permutes
     uint32_t bits = 0;
-    while (bits < 31 && ((int64_t)1 << bits) < h->cfg.nnz) ++bits;
+    while (bits < 31 && ((int64_t)1 << bits) < domain) ++bits;
     p.bij_mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
     p.bij_shift = bits > 1 ? bits / 2 : 1;
     // SplitMix64 of (seed, iteration) -> four round keys
@@ -677,9 +703,11 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     GE_TRY(hipMalloc((void **)&h->dX, sizeof(float) * nn));
     GE_TRY(hipMalloc((void **)&h->dcost, 2 * sizeof(double)));
     GE_TRY(hipMalloc((void **)&h->djob, sizeof(float) * (size_t)cfg->threads));
-    std::vector<int32_t> jmarked;     // J with hot columns complemented (kept alive until the copy is done)
+    h->host_key.clear(); h->host_border.clear();
+    std::vector<float> bX;            // blocked order: X per re-ordered position
     if (cfg->mode == GE_MODE_HOGWILD) {
         if (const char *e = std::getenv("GE_GLOVE_BLOCKS_PER_CU")) h->hw_blocks_per_cu = std::max(1, std::atoi(e));
+        if (const char *e = std::getenv("GE_GLOVE_FLUSH_EVERY")) h->flush_every = std::max(1, std::atoi(e));
         h->hw_fn = pick_hogwild(D, &h->hw_vw, &h->hw_nch);
         if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 1024 for dim%%4==0, 256 for odd dim)", D); }
         // One wavefront = one sequential worker.  Never more workers than N/2048: a small matrix must
@@ -697,33 +725,99 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
             h->hw_workers = (int)std::min<int64_t>(cfg->workers, (int64_t)h->num_cus * 32);
             h->hw_blocks = (h->hw_workers + 3) / 4;
         }
+        // ---- hub columns --------------------------------------------------------------------------
+        std::vector<int32_t> cnt((size_t)V, 0);
+        std::vector<uint8_t> hotcol((size_t)V, 0);
         if (N > 0 && cfg->hot_columns != GE_HOT_NONE) {
             double theta = 0.25;
             if (const char *e = std::getenv("GE_GLOVE_HOT_THETA")) theta = std::atof(e);
             const int64_t inflight = h->hw_workers;
-            int64_t thr = cfg->hot_columns == GE_HOT_ALL ? 0
-                        : std::max<int64_t>(2, (int64_t)std::ceil(theta * (double)N / (double)inflight));
-            std::vector<int32_t> cnt((size_t)V, 0);
+            const int64_t thr = cfg->hot_columns == GE_HOT_ALL ? 0
+                              : std::max<int64_t>(2, (int64_t)std::ceil(theta * (double)N / (double)inflight));
             for (int64_t k = 0; k < N; ++k) ++cnt[(size_t)J[k]];
-            jmarked.assign(J, J + N);
-            for (int64_t k = 0; k < N; ++k)
-                if (cnt[(size_t)J[k]] >= thr) { jmarked[(size_t)k] = ~J[k]; ++h->hot_nnz; }
-            for (int32_t v = 0; v < V; ++v) if (cnt[(size_t)v] >= thr && cnt[(size_t)v] > 0) ++h->hot_cols;
+            for (int32_t v = 0; v < V; ++v)
+                if (cnt[(size_t)v] >= thr && cnt[(size_t)v] > 0) { hotcol[(size_t)v] = 1; ++h->hot_cols; h->hot_nnz += cnt[(size_t)v]; }
             h->hot_threshold = thr;
+        }
+        // Concurrent runs on one hub column add their deltas; each delta is stale by the length of the run.
+        // Summing K concurrent runs of m updates behaves like one step K*m times too long, and diverges
+        // once K*m*(lr*w*|row|^2) passes ~1 (measured: K*m = 39k diverges, 10k is stable at the bench
+        // scale).  A hub run is therefore cut -- delta published, row re-read -- every m_j updates with
+        // K_j * m_j <= stale_budget, K_j = expected workers inside column j = count_j * workers / N.
+        double stale_budget = 2000.0;
+        if (const char *e = std::getenv("GE_GLOVE_STALE_BUDGET")) stale_budget = std::max(1.0, std::atof(e));
+        auto flush_limit = [&](int32_t col) -> int32_t {
+            const double K = std::max(1.0, (double)cnt[(size_t)col] * (double)h->hw_workers / (double)std::max<int64_t>(N, 1));
+            const double m = std::floor(stale_budget / K);
+            return (int32_t)std::min<double>(RUN_CHUNK, std::max<double>(4.0, m));
+        };
+        if (!std::getenv("GE_GLOVE_FLUSH_EVERY")) {
+            int32_t m_min = RUN_CHUNK;
+            for (int32_t v = 0; v < V; ++v) if (hotcol[(size_t)v]) m_min = std::min(m_min, flush_limit(v));
+            h->flush_every = m_min;
+        }
+        h->blocked = cfg->shuffle == GE_SHUFFLE_DEVICE;
+        if (!h->blocked) {
+            // general order (Java permutation / matrix order): hub columns are keyed ~j
+            h->host_key.assign(J, J + N);
+            for (int64_t k = 0; k < N; ++k) if (hotcol[(size_t)J[k]]) h->host_key[(size_t)k] = ~J[k];
+            h->n_chunks = chunks; h->n_hchunks = 0;
+        } else {
+            // Blocked order.  H = nonzeros of the hub columns, column-major (stable counting sort by j);
+            // R = the rest in matrix order, i.e. row-major as BookmarkColoring emits it.  Both are padded to
+            // whole chunks of 128; a chunk is the unit the epoch order permutes.
+            const int64_t nH = h->hot_nnz, nR = N - nH;
+            const int64_t Hpad = (nH + RUN_CHUNK - 1) / RUN_CHUNK * RUN_CHUNK, Rpad = (nR + RUN_CHUNK - 1) / RUN_CHUNK * RUN_CHUNK;
+            const size_t tot = (size_t)(Hpad + Rpad);
+            h->host_key.assign(tot, KEY_PAD);          // resident row id per position
+            h->host_border.assign(tot, -1);            // original nonzero per position
+            std::vector<int32_t> bB(tot, 0);
+            bX.assign(tot, 0.5f);
+            std::vector<int64_t> start((size_t)V + 1, 0);
+            for (int32_t v = 0; v < V; ++v) start[(size_t)v + 1] = start[(size_t)v] + (hotcol[(size_t)v] ? cnt[(size_t)v] : 0);
+            int64_t r = Hpad;
+            for (int64_t k = 0; k < N; ++k) {
+                const int32_t j = J[k];
+                size_t pos;
+                if (hotcol[(size_t)j]) { pos = (size_t)start[(size_t)j]++; h->host_key[pos] = j; bB[pos] = I[k]; }
+                else { pos = (size_t)r++; h->host_key[pos] = I[k]; bB[pos] = j; }
+                h->host_border[pos] = (int32_t)k; bX[pos] = X[k];
+            }
+            h->n_chunks = (int64_t)tot / RUN_CHUNK; h->n_hchunks = Hpad / RUN_CHUNK;
+            std::vector<int32_t> cf((size_t)std::max<int64_t>(h->n_hchunks, 1), RUN_CHUNK);
+            for (int64_t c = 0; c < h->n_hchunks; ++c) {
+                int32_t m = RUN_CHUNK;
+                for (int64_t k = c * RUN_CHUNK; k < (c + 1) * RUN_CHUNK; ++k)
+                    if (h->host_key[(size_t)k] != KEY_PAD) m = std::min(m, std::getenv("GE_GLOVE_FLUSH_EVERY") ? h->flush_every : flush_limit(h->host_key[(size_t)k]));
+                cf[(size_t)c] = m;
+            }
+            GE_TRY(hipMalloc((void **)&h->dchunk_flush, sizeof(int32_t) * cf.size()));
+            GE_TRY(hipMemcpy(h->dchunk_flush, cf.data(), sizeof(int32_t) * cf.size(), hipMemcpyHostToDevice));
+            GE_TRY(hipMalloc((void **)&h->dbA, sizeof(int32_t) * std::max<size_t>(tot, 1)));
+            GE_TRY(hipMalloc((void **)&h->dbB, sizeof(int32_t) * std::max<size_t>(tot, 1)));
+            if (tot) {
+                GE_TRY(hipMemcpy(h->dbA, h->host_key.data(), sizeof(int32_t) * tot, hipMemcpyHostToDevice));
+                GE_TRY(hipMemcpy(h->dbB, bB.data(), sizeof(int32_t) * tot, hipMemcpyHostToDevice));
+            }
         }
     } else if ((size_t)D * sizeof(float) > 64 * 1024) {
         ge_glove_destroy(h);
         return ge::fail(GE_ERR_ARG, "dim %d too large for deterministic mode", D);
     }
     if (N > 0) {
-        GE_TRY(hipMemcpyAsync(h->dI, I, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
-        GE_TRY(hipMemcpyAsync(h->dJ, jmarked.empty() ? J : jmarked.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
-        GE_TRY(hipMemcpyAsync(h->dX, X, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+        const bool blocked = cfg->mode == GE_MODE_HOGWILD && h->blocked;
+        const size_t nx = blocked ? bX.size() : (size_t)N;
+        if (blocked && nx > nn) { (void)hipFree(h->dX); h->dX = nullptr; GE_TRY(hipMalloc((void **)&h->dX, sizeof(float) * nx)); }
+        if (!blocked) {
+            GE_TRY(hipMemcpyAsync(h->dI, I, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+            GE_TRY(hipMemcpyAsync(h->dJ, h->host_key.empty() ? J : h->host_key.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+        }
+        GE_TRY(hipMemcpyAsync(h->dX, blocked ? bX.data() : X, sizeof(float) * nx, hipMemcpyHostToDevice, h->stream));
         if (cfg->mode == GE_MODE_HOGWILD) {
-            GE_TRY(hipMalloc((void **)&h->dL, sizeof(double) * nn));
-            GE_TRY(hipMalloc((void **)&h->dW, sizeof(float) * nn));
-            const int blocks = (int)std::min<int64_t>((N + 255) / 256, 8192);
-            hipLaunchKernelGGL(k_cost_terms, dim3(blocks), dim3(256), 0, h->stream, h->dX, N, cfg->cost, cfg->xmax, h->dL, h->dW);
+            GE_TRY(hipMalloc((void **)&h->dL, sizeof(double) * nx));
+            GE_TRY(hipMalloc((void **)&h->dW, sizeof(float) * nx));
+            const int blocks = (int)std::min<int64_t>(((int64_t)nx + 255) / 256, 8192);
+            hipLaunchKernelGGL(k_cost_terms, dim3(blocks), dim3(256), 0, h->stream, h->dX, (int64_t)nx, cfg->cost, cfg->xmax, h->dL, h->dW);
         }
         GE_TRY(hipStreamSynchronize(h->stream));
     }
@@ -814,7 +908,7 @@ ge_status ge_glove_epoch(ge_glove *h, int32_t iteration, double *cost_sum) {
         GE_HIP(hipMemsetAsync(h->dcost, 0, 2 * sizeof(double), h->stream));
         GE_HIP(hipEventRecord(h->ev0, h->stream));
         if (N > 0) {
-            hipLaunchKernelGGL(h->hw_fn, dim3(h->hw_blocks), dim3(256), 0, h->stream, p, (int64_t)0, N, h->cfg.vocab_size, (int32_t)h->hw_workers);
+            hipLaunchKernelGGL(h->hw_fn, dim3(h->hw_blocks), dim3(256), 0, h->stream, p, (int32_t)h->hw_workers);
             ++h->last_launches;
         }
         GE_HIP(hipEventRecord(h->ev1, h->stream));
@@ -886,6 +980,35 @@ ge_status ge_glove_get_perm(ge_glove *h, int32_t *out, int64_t count) {
     return GE_OK;
 }
 
+ge_status ge_glove_epoch_order(ge_glove *h, int32_t iteration, int32_t *out, int64_t count) {
+    if (!h || !out) return ge::fail(GE_ERR_ARG, "null argument");
+    if (h->cfg.mode != GE_MODE_HOGWILD) return ge::fail(GE_ERR_STATE, "epoch order is defined for GE_MODE_HOGWILD handles");
+    const int64_t N = h->cfg.nnz;
+    if (count != N) return ge::fail(GE_ERR_ARG, "the epoch visits %lld nonzeros", (long long)N);
+    GloveParams p;
+    fill_params(h, p, iteration);
+    std::vector<std::pair<int32_t, int32_t>> ent;      // (key, original nonzero) of one chunk, in staging order
+    int64_t w = 0;
+    for (int64_t t = 0; t < h->n_chunks; ++t) {
+        ent.clear();
+        if (h->blocked) {
+            uint32_t x = (uint32_t)t;
+            do { x = bij_round(x, p); } while ((int64_t)x >= h->n_chunks);
+            for (int64_t k = (int64_t)x * RUN_CHUNK; k < ((int64_t)x + 1) * RUN_CHUNK; ++k)
+                if (h->host_key[(size_t)k] != KEY_PAD) ent.push_back({h->host_key[(size_t)k], h->host_border[(size_t)k]});
+        } else {
+            for (int64_t k = t * RUN_CHUNK; k < std::min<int64_t>((t + 1) * RUN_CHUNK, N); ++k) {
+                const int64_t idx = h->cfg.shuffle == GE_SHUFFLE_JAVA ? h->perm[(size_t)k] : k;
+                ent.push_back({h->host_key[(size_t)idx], (int32_t)idx});
+            }
+        }
+        std::stable_sort(ent.begin(), ent.end(), [](const std::pair<int32_t, int32_t> &a, const std::pair<int32_t, int32_t> &b) { return a.first < b.first; });
+        for (auto &e : ent) out[w++] = e.second;
+    }
+    if (w != N) return ge::fail(GE_ERR_STATE, "internal: epoch order covers %lld of %lld nonzeros", (long long)w, (long long)N);
+    return GE_OK;
+}
+
 ge_status ge_glove_rng_state(ge_glove *h, uint64_t *state) {
     if (!h || !state) return ge::fail(GE_ERR_ARG, "null argument");
     *state = h->rng.s;
@@ -917,6 +1040,9 @@ void ge_glove_destroy(ge_glove *h) {
     if (h->dJ) (void)hipFree(h->dJ);
     if (h->dX) (void)hipFree(h->dX);
     if (h->dperm) (void)hipFree(h->dperm);
+    if (h->dbA) (void)hipFree(h->dbA);
+    if (h->dbB) (void)hipFree(h->dbB);
+    if (h->dchunk_flush) (void)hipFree(h->dchunk_flush);
     if (h->dL) (void)hipFree(h->dL);
     if (h->dW) (void)hipFree(h->dW);
     if (h->dcost) (void)hipFree(h->dcost);

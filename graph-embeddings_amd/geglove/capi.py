@@ -25,7 +25,7 @@ STATE_NAMES = ("focus", "context", "fbias", "cbias", "gsq_focus", "gsq_context",
 SYMBOLS = (
     "ge_glove_cfg_default", "ge_glove_create", "ge_glove_epoch", "ge_glove_extract_f32",
     "ge_glove_extract_f64", "ge_glove_get_state", "ge_glove_set_state", "ge_glove_device_ptr",
-    "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
+    "ge_glove_epoch_order", "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
     "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_last_error", "ge_version", "ge_device_count",
 )
 
@@ -84,6 +84,7 @@ def lib():
     L.ge_glove_get_state.argtypes = [vp, C.c_int32, f32p, C.c_int64]
     L.ge_glove_set_state.argtypes = [vp, C.c_int32, f32p, C.c_int64]
     L.ge_glove_device_ptr.argtypes = [vp, C.c_int32, C.POINTER(vp), i64p]
+    L.ge_glove_epoch_order.argtypes = [vp, C.c_int32, i32p, C.c_int64]
     L.ge_glove_get_perm.argtypes = [vp, i32p, C.c_int64]
     L.ge_glove_rng_state.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.ge_glove_last_kernel_ms.argtypes = [vp, f32p, i32p]

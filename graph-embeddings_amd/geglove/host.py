@@ -316,6 +316,12 @@ class Adagrad:
         capi.check(capi.lib().ge_glove_get_perm(self._h, _p(out, C.c_int32), self.coCount))
         return out
 
+    def epoch_order(self, iteration):
+        """Order in which a single worker walks the nonzeros in epoch `iteration` (ge_glove_epoch_order)."""
+        out = np.empty(self.coCount, np.int32)
+        capi.check(capi.lib().ge_glove_epoch_order(self._h, iteration, _p(out, C.c_int32), self.coCount))
+        return out
+
     def rng_state(self):
         s = C.c_uint64()
         capi.check(capi.lib().ge_glove_rng_state(self._h, C.byref(s)))

@@ -57,8 +57,12 @@ enum { GE_MODE_HOGWILD = 0, GE_MODE_DETERMINISTIC = 1 };
  * JAVA:   CoOccurrenceMatrix.shuffle() = cumulative forward Fisher-Yates on one permutation,
  *         drawn from the SAME java.util.Random stream that initialised the parameters
  *         (J/opt/Optimizer.java:79; J/util/rnd/Permutation.java:21; ExtendedRandom.java:398-407).
- * DEVICE: a fresh keyed bijection of [0, N) per epoch evaluated inside the kernel (no
- *         permutation array, no host work) -- statistically equivalent, not the Java order.
+ * DEVICE: (HOGWILD) the matrix is cut once into chunks of 128 nonzeros -- hub columns column-major, the
+ *         rest row-major as BookmarkColoring emits it -- and every epoch visits the chunks in a fresh
+ *         keyed-bijection order evaluated inside the kernel (no permutation array, no host work).  One
+ *         side of each update then stays in registers for a whole run, which halves the HBM traffic.
+ *         Not the Java order; measured statistically equivalent.  (DETERMINISTIC: a keyed
+ *         bijection of the nonzeros themselves.)
  * NONE:   matrix order (no shuffle). */
 enum { GE_SHUFFLE_JAVA = 0, GE_SHUFFLE_DEVICE = 1, GE_SHUFFLE_NONE = 2 };
 
@@ -154,6 +158,12 @@ ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_
 /* Raw device pointer of a table (for zero-copy wrapping by the host runtime, e.g. the
  * torch.distributed/RCCL all-reduce of the context factors). Valid until destroy. */
 ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *count);
+
+/* The order in which ONE worker (cfg.workers = 1) walks the nonzeros in epoch `iteration` of a HOGWILD handle:
+ * out[k] = index into the caller's I/J/X of the k-th update.  With more workers the same chunks of 128 are
+ * handed out in this order but run concurrently.  (GE_SHUFFLE_JAVA: the order of the most recent epoch.)
+ * Lets a sequential implementation replay the device pass exactly (parity tests). */
+ge_status ge_glove_epoch_order(ge_glove *h, int32_t iteration, int32_t *out, int64_t count);
 
 /* Current permutation (GE_SHUFFLE_JAVA only) and java.util.Random state, for parity tests. */
 ge_status ge_glove_get_perm(ge_glove *h, int32_t *out, int64_t count);
