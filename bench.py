@@ -157,6 +157,17 @@ def main():
         total_updates = float(u.item())
 
     if rank == 0:
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
+        # correction + WRITE_SIZE), valid only for the exact workload they were taken on
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                for t in json.load(open(tpath)):
+                    if (t["vocab"], t["nnz_per_gpu"], t["dim"], t["cost"]) == (V, n_local, D, args.method) and world == 1:
+                        traffic = t["traffic_bytes_per_launch"]
+            except Exception:
+                traffic = None
         read_b, write_b = 16 * D + 28, 16 * D + 16
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
         ach = n_local * (read_b + write_b) / avg_kernel_s / 1e9          # GB/s, rank 0's kernel
@@ -175,13 +186,14 @@ def main():
                        "parallelism": "rows sharded x%d, context replicated + delta all-reduce (mean over contributing ranks) every %d step(s)"
                                       % (world, args.sync_every) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
-                         "traffic": None,
-                         "kernel": "k_adagrad_hogwild", "kernel_ms": avg_kernel_s * 1e3,
+                         "traffic": traffic,
+                         "kernel": "k_adagrad_runs", "algorithmic_bytes_per_launch": n_local * (read_b + write_b), "kernel_ms": avg_kernel_s * 1e3,
                          "bytes_per_update": {"read": read_b, "write": write_b},
                          "achieved_read": n_local * read_b / avg_kernel_s / 1e9,
                          "frac_read": n_local * read_b / avg_kernel_s / 1e9 / 8000.0,
                          "kernel_updates_per_s": n_local / avg_kernel_s},
             "mean_cost_first_last": [costs[0] / n_local, costs[-1] / n_local],
+            "trainer": opt.info(),
             "gen_seconds": t_gen,
         }
         if world == 1 and not args.no_cpu_baseline:
