@@ -11,6 +11,20 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))    # import helpe
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _build_if_missing()
+
+
+def _build_if_missing():
+    """The shared libraries are build products (git-ignored).  A fresh checkout builds them once, here;
+    on the GPU box they arrive pre-built with the snapshot (hipcc cross-compiles gfx950 without a GPU)."""
+    import subprocess
+    pkg = os.path.join(REPO, "graph-embeddings_amd")
+    need = [(os.path.join(pkg, "lib", "libgeglove.so"), os.path.join(pkg, "csrc")),
+            (os.path.join(pkg, "lib", "libgehost.so"), os.path.join(pkg, "host")),
+            (os.path.join(REPO, "oracle", "libge_oracle.so"), os.path.join(REPO, "oracle"))]
+    for lib, src in need:
+        if not os.path.exists(lib):
+            subprocess.check_call(["make", "-C", src, "-j4"])
 
 
 def _has_gpu():
