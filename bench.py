@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--hot", default="auto", choices=["auto", "none", "all"])
+    ap.add_argument("--opt", default="adagrad", choices=["adagrad", "adam", "amsgrad"],
+                    help="update rule (the headline metric is quoted on adagrad; adam/amsgrad keep two moment rows per side)")
     ap.add_argument("--sync-every", type=int, default=1, help="steps between context all-reduces (N>1)")
     return ap.parse_args()
 
@@ -103,11 +105,11 @@ def main():
     cfg = geglove.Configuration({
         "graph": "synthetic", "method": args.method, "dim": D, "threads": 1,
         "bca": {"alpha": 0.1, "epsilon": 1e-3, "directed": True},
-        "opt": {"method": "adagrad", "tolerance": 0, "maxiter": args.steps},
+        "opt": {"method": args.opt, "tolerance": 0, "maxiter": args.steps},
         "output": {"uri": []},
         "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot,
                    "row_range": rows if world > 1 else (0, 0)}})
-    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+    opt = geglove.createOptimizer(cfg, geglove.CooMatrix(V, I, J, X, xmax))
 
     sync = None
     if world > 1:
@@ -164,11 +166,12 @@ def main():
         if os.path.exists(tpath):
             try:
                 for t in json.load(open(tpath)):
-                    if (t["vocab"], t["nnz_per_gpu"], t["dim"], t["cost"]) == (V, n_local, D, args.method) and world == 1:
+                    if (t["vocab"], t["nnz_per_gpu"], t["dim"], t["cost"]) == (V, n_local, D, args.method) and world == 1 and args.opt == "adagrad":
                         traffic = t["traffic_bytes_per_launch"]
             except Exception:
                 traffic = None
-        read_b, write_b = 16 * D + 28, 16 * D + 16
+        # algorithmic bytes per pair-update (8f for the moment optimisers: one more row per side)
+        read_b, write_b = (16 * D + 28, 16 * D + 16) if args.opt == "adagrad" else (24 * D + 36, 24 * D + 24)
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
         ach = n_local * (read_b + write_b) / avg_kernel_s / 1e9          # GB/s, rank 0's kernel
         out = {
@@ -180,9 +183,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic hub-heavy co-occurrence matrix (BASELINE C4 recipe scaled to %d GPU%s): "
-                                   "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, AdaGrad Hogwild, per-epoch device shuffle"
-                                   % (world, "s" if world > 1 else "", V, n_local, D, args.method),
-                       "vocab": V, "nnz_per_gpu": n_local, "dim": D, "cost": args.method,
+                                   "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, %s Hogwild, per-epoch device shuffle"
+                                   % (world, "s" if world > 1 else "", V, n_local, D, args.method, opt.getName()),
+                       "vocab": V, "nnz_per_gpu": n_local, "dim": D, "cost": args.method, "opt": args.opt,
                        "parallelism": "rows sharded x%d, context replicated + delta all-reduce (mean over contributing ranks) every %d step(s)"
                                       % (world, args.sync_every) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,

@@ -29,7 +29,10 @@ enum { ORDER_IDENTITY = 0, ORDER_PERM = 1, ORDER_BIJECTION = 2 };
 
 struct GloveParams {
     float *focus, *context, *fbias, *cbias;
-    float *gsf, *gsc, *gsfb, *gscb;
+    float *gsf, *gsc, *gsfb, *gscb;          // Adagrad.gradSq* | Adam/AMSGrad.M1*
+    float *m2f, *m2c, *m2fb, *m2cb;          // Adam/AMSGrad.M2*
+    double correction;                       // Adam: lr*sqrt(1-beta2^(t+1))/(1-beta1^(t+1))  (Adam.java:84), per epoch
+    int32_t opt;                             // GE_OPT_*
     const int32_t *I, *J;
     const float *X;
     const int32_t *perm;
@@ -169,21 +172,57 @@ __global__ __launch_bounds__(64) void k_adagrad_exact(GloveParams p, int64_t k_b
         float wc = w * ic;
         cost = (float)((double)cost + (0.5 * (double)wc) * (double)ic);
         __syncthreads();
-        for (int32_t d = lane; d < D; d += 64) {
-            const float f = foc[d], c = ctx[d];
-            const float grad1 = wc * c;
-            const float grad2 = wc * f;
-            foc[d] = (float)((double)f - ((double)grad1 / sqrt((double)g1s[d])) * lr);
-            ctx[d] = (float)((double)c - ((double)grad2 / sqrt((double)g2s[d])) * lr);
-            g1s[d] = g1s[d] + grad1 * grad1;
-            g2s[d] = g2s[d] + grad2 * grad2;
-        }
-        if (lane == 0) {
-            p.fbias[bu] = (float)((double)p.fbias[bu] - (double)wc / sqrt((double)p.gsfb[bu]));
-            p.cbias[bv] = (float)((double)p.cbias[bv] - (double)wc / sqrt((double)p.gscb[bv]));
-            wc = wc * wc;
-            p.gsfb[bu] = p.gsfb[bu] + wc;
-            p.gscb[bv] = p.gscb[bv] + wc;
+        if (p.opt == GE_OPT_ADAGRAD) {
+            for (int32_t d = lane; d < D; d += 64) {
+                const float f = foc[d], c = ctx[d];
+                const float grad1 = wc * c;
+                const float grad2 = wc * f;
+                foc[d] = (float)((double)f - ((double)grad1 / sqrt((double)g1s[d])) * lr);
+                ctx[d] = (float)((double)c - ((double)grad2 / sqrt((double)g2s[d])) * lr);
+                g1s[d] = g1s[d] + grad1 * grad1;
+                g2s[d] = g2s[d] + grad2 * grad2;
+            }
+            if (lane == 0) {
+                p.fbias[bu] = (float)((double)p.fbias[bu] - (double)wc / sqrt((double)p.gsfb[bu]));
+                p.cbias[bv] = (float)((double)p.cbias[bv] - (double)wc / sqrt((double)p.gscb[bv]));
+                wc = wc * wc;
+                p.gsfb[bu] = p.gsfb[bu] + wc;
+                p.gscb[bv] = p.gscb[bv] + wc;
+            }
+        } else {
+            // Adam.java:103-145 / AMSGrad.java:117-160.  All moment arithmetic is fp32 (beta1, 1-beta1, ... are floats),
+            // the parameter step goes through fp64 exactly as `focus[d1] -= correction * m1 / (sqrt(v1) + epsilon)`.
+            const bool ams = p.opt == GE_OPT_AMSGRAD;
+            const float beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-7f;
+            const float omb1 = 1 - beta1, omb2 = 1 - beta2;
+            float *m2f = p.m2f + (int64_t)bu * D, *m2c = p.m2c + (int64_t)bv * D;
+            auto fmaxj = [](float a, float b) { return (a <= b) ? b : ((a + b) != (a + b) ? __builtin_nanf("") : a); };   // FastMath.max
+            auto step = [&](float par, float m, float v) -> float {
+                return ams ? (float)((double)par - lr / (sqrt((double)v) + (double)epsilon) * (double)m)
+                           : (float)((double)par - p.correction * (double)m / (sqrt((double)v) + (double)epsilon));
+            };
+            for (int32_t d = lane; d < D; d += 64) {
+                const float f = foc[d], c = ctx[d];
+                const float grad_u = wc * c, grad_v = wc * f;
+                const float m1 = beta1 * g1s[d] + omb1 * grad_u;
+                const float m2 = beta1 * g2s[d] + omb1 * grad_v;
+                float v1 = beta2 * m2f[d] + omb2 * (grad_u * grad_u);
+                float v2 = beta2 * m2c[d] + omb2 * (grad_v * grad_v);
+                if (ams) { v1 = fmaxj(m2f[d], v1); v2 = fmaxj(m2c[d], v2); }
+                foc[d] = step(f, m1, v1);
+                ctx[d] = step(c, m2, v2);
+                g1s[d] = m1; g2s[d] = m2; m2f[d] = v1; m2c[d] = v2;
+            }
+            if (lane == 0) {
+                const float m1 = beta1 * p.gsfb[bu] + omb1 * wc;
+                const float m2 = beta1 * p.gscb[bv] + omb1 * wc;
+                float v1 = beta2 * p.m2fb[bu] + omb2 * (wc * wc);
+                float v2 = beta2 * p.m2cb[bv] + omb2 * (wc * wc);
+                if (ams) { v1 = fmaxj(p.m2fb[bu], v1); v2 = fmaxj(p.m2cb[bv], v2); }
+                p.fbias[bu] = step(p.fbias[bu], m1, v1);
+                p.cbias[bv] = step(p.cbias[bv], m2, v2);
+                p.gsfb[bu] = m1; p.gscb[bv] = m2; p.m2fb[bu] = v1; p.m2cb[bv] = v2;
+            }
         }
         __syncthreads();   // the next nonzero may read what this one wrote (same wave, program order)
     }
@@ -271,9 +310,20 @@ __device__ __forceinline__ float wave_sum(float v) {
 constexpr int RUN_CHUNK = 128;            // nonzeros per worker chunk (2 per lane)
 constexpr int KEY_PAD = 0x7FFFFFFF;       // sorts last; marks the unused tail of the last chunk
 
-template <int VW, int NCH>
+// OPT: GE_OPT_ADAGRAD keeps one auxiliary row per side (gradSq), Adam / AMSGrad two (M1, M2).
+template <int VW, int NCH, int OPT>
 __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_workers) {
     using VT = typename Vec<VW>::T;
+    constexpr bool MOM = OPT != GE_OPT_ADAGRAD;
+    constexpr float BETA1 = 0.9f, BETA2 = 0.999f, EPS = 1e-7f, OMB1 = 1 - BETA1, OMB2 = 1 - BETA2;   // Adam.java:45-53
+    const float corr = OPT == GE_OPT_ADAM ? (float)p.correction : p.lr;      // Adam.java:84 | AMSGrad.java:133 uses lr itself
+    // one element of an Adam / AMSGrad update in fp32: new moments and the parameter step
+    auto moment_step = [&](float grad, float &m, float &v) -> float {
+        m = __builtin_fmaf(BETA1, m, OMB1 * grad);
+        const float vn = __builtin_fmaf(BETA2, v, OMB2 * (grad * grad));
+        v = OPT == GE_OPT_AMSGRAD ? fmaxf(v, vn) : vn;
+        return corr * m * __frcp_rn(__fsqrt_rn(v) + EPS);
+    };
     const int lane = threadIdx.x & 63;
     const int32_t D = p.D;
     const uint32_t row_bytes = (uint32_t)D * 4u;
@@ -310,7 +360,6 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             chunk = rfl((int)x);
             res_is_ctx = chunk < p.n_hchunks;
         }
-        const int flush_every = (p.blocked && res_is_ctx) ? p.chunk_flush[chunk] : p.flush_every;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int64_t k = chunk * RUN_CHUNK + q * 64 + lane;
@@ -358,22 +407,30 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
         float *const A_bias = res_is_ctx ? p.cbias : p.fbias,  *const A_gsb = res_is_ctx ? p.gscb : p.gsfb;
         float *const B_rows = res_is_ctx ? p.focus : p.context, *const B_gs = res_is_ctx ? p.gsf : p.gsc;
         float *const B_bias = res_is_ctx ? p.fbias : p.cbias,  *const B_gsb = res_is_ctx ? p.gsfb : p.gscb;
+        float *const A_m2 = res_is_ctx ? p.m2c : p.m2f,  *const A_m2b = res_is_ctx ? p.m2cb : p.m2fb;     // MOM only
+        float *const B_m2 = res_is_ctx ? p.m2f : p.m2c,  *const B_m2b = res_is_ctx ? p.m2fb : p.m2cb;
 
         // ---- sequential walk ---------------------------------------------------------------------
         // Software pipeline: while nonzero `pos` is computed, the streamed rows of pos+1 and (when the
         // resident row changes there) its resident rows are already in flight.  They are requested BEFORE
         // this nonzero's stores, so waiting for them never waits for a store to retire.
         int32_t cur_id = 0; bool cur_hot = false;
-        VT a[NCH], ga[NCH], a0[NCH], ga0[NCH];
-        float ab = 0.0f, gab = 0.0f;
-        __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A_rows, 0), rs_ga = rs_a;
+        VT a[NCH], ga[NCH], ha[NCH], a0[NCH], ga0[NCH];     // ha = second moment (MOM); ga0 = gradSq as read (AdaGrad)
+        float ab = 0.0f, gab = 0.0f, hab = 0.0f;
+        __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A_rows, 0), rs_ga = rs_a, rs_ha = rs_a;
 
         auto close_run = [&]() {
-            if (!cur_hot) {
+            // Adam / AMSGrad take steps of about the learning rate whatever the gradient's size, so concurrent hub
+            // runs must not ADD their moves (measured: the cost climbs again after a few epochs); they are merged
+            // last-writer-wins, parameters and moments alike, which is exactly the Java race.  The run is still cut
+            // and re-read every flush_every nonzeros, so workers on one hub stay within that many updates of
+            // each other.
+            if (!cur_hot || MOM) {
 #pragma unroll
                 for (int q = 0; q < NCH; ++q) {
                     buf_store<VW>(a[q], rs_a, (lane + q * 64) * VW * 4);
                     buf_store<VW>(ga[q], rs_ga, (lane + q * 64) * VW * 4);
+                    if constexpr (MOM) buf_store<VW>(ha[q], rs_ha, (lane + q * 64) * VW * 4);
                 }
             } else {
                 // Publish the run's delta with float atomics.  Lane L holds elements [VW*L, VW*L+VW);
@@ -386,10 +443,16 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
 #pragma unroll
                     for (int t = 0; t < VW; ++t) {
                         comp<VW>(dc, t) = comp<VW>(a[q], t) - comp<VW>(a0[q], t);
-                        comp<VW>(dg, t) = comp<VW>(ga[q], t) - comp<VW>(ga0[q], t);
+                        if constexpr (!MOM) comp<VW>(dg, t) = comp<VW>(ga[q], t) - comp<VW>(ga0[q], t);
                     }
                     *reinterpret_cast<VT *>(tr_c + (lane + q * 64) * VW) = dc;
-                    *reinterpret_cast<VT *>(tr_g + (lane + q * 64) * VW) = dg;
+                    if constexpr (!MOM) *reinterpret_cast<VT *>(tr_g + (lane + q * 64) * VW) = dg;
+                    // Adam / AMSGrad moments are running averages, not sums: concurrent hub runs merge them
+                    // last-writer-wins (like the biases); only the parameter row is published additively.
+                    if constexpr (MOM) {
+                        buf_store<VW>(ga[q], rs_ga, (lane + q * 64) * VW * 4);
+                        buf_store<VW>(ha[q], rs_ha, (lane + q * 64) * VW * 4);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -398,7 +461,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
                 for (int k = 0; k < NCH * VW; ++k) {
                     const int e = lane + k * 64;          // element index; past D the buffer check drops it
                     __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_c[e], rs_a, e * 4, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_g[e], rs_ga, e * 4, 0, 0);
+                    if constexpr (!MOM) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_g[e], rs_ga, e * 4, 0, 0);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -408,14 +471,15 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             if (lane == 0) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ab), make_rsrc(A_bias + cur_id, 4), 0, 0, AUX_SC1);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gab), make_rsrc(A_gsb + cur_id, 4), 0, 0, AUX_SC1);
+                if constexpr (MOM) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hab), make_rsrc(A_m2b + cur_id, 4), 0, 0, AUX_SC1);
             }
         };
 
         // decoded next nonzero + its prefetched rows
         int32_t n_oth = 0, n_key = KEY_PAD; float n_w = 0.0f; double n_l = 0.0;
-        VT nb[NCH], ngb[NCH]; float n_bb = 0.0f, n_gbb = 0.0f;
-        VT aN[NCH], gaN[NCH]; float abN = 0.0f, gabN = 0.0f;
-        __amdgpu_buffer_rsrc_t rsN_a = rs_a, rsN_ga = rs_a;
+        VT nb[NCH], ngb[NCH], nhb[NCH]; float n_bb = 0.0f, n_gbb = 0.0f, n_hbb = 0.0f;
+        VT aN[NCH], gaN[NCH], haN[NCH]; float abN = 0.0f, gabN = 0.0f, habN = 0.0f;
+        __amdgpu_buffer_rsrc_t rsN_a = rs_a, rsN_ga = rs_a, rsN_ha = rs_a;
         auto decode = [&](int pos) {
             const int q = pos >> 6, ln = pos & 63;
             n_key = __builtin_amdgcn_readlane(q ? key[1] : key[0], ln);
@@ -431,25 +495,31 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
         auto request_streamed = [&]() {
             const __amdgpu_buffer_rsrc_t rb = make_rsrc(B_rows + (int64_t)n_oth * D, row_bytes);
             const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)n_oth * D, row_bytes);
+            const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)n_oth * D, MOM ? row_bytes : 0u);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
                 nb[q]  = buf_load<VW, AUX_SC1>(rb, (lane + q * 64) * VW * 4);
                 ngb[q] = buf_load<VW, AUX_SC1>(rg, (lane + q * 64) * VW * 4);
+                if constexpr (MOM) nhb[q] = buf_load<VW, AUX_SC1>(rh, (lane + q * 64) * VW * 4);
             }
             n_bb  = buf_load_f32(make_rsrc(B_bias + n_oth, 4), 0, true);
             n_gbb = buf_load_f32(make_rsrc(B_gsb + n_oth, 4), 0, true);
+            if constexpr (MOM) n_hbb = buf_load_f32(make_rsrc(B_m2b + n_oth, 4), 0, true);
         };
         auto request_resident = [&]() {
             const int32_t id = n_key < 0 ? ~n_key : n_key;
             rsN_a = make_rsrc(A_rows + (int64_t)id * D, row_bytes);
             rsN_ga = make_rsrc(A_gs + (int64_t)id * D, row_bytes);
+            rsN_ha = make_rsrc(A_m2 + (int64_t)id * D, MOM ? row_bytes : 0u);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
                 aN[q]  = buf_load<VW, AUX_SC1>(rsN_a, (lane + q * 64) * VW * 4);
                 gaN[q] = buf_load<VW, AUX_SC1>(rsN_ga, (lane + q * 64) * VW * 4);
+                if constexpr (MOM) haN[q] = buf_load<VW, AUX_SC1>(rsN_ha, (lane + q * 64) * VW * 4);
             }
             abN  = buf_load_f32(make_rsrc(A_bias + id, 4), 0, true);
             gabN = buf_load_f32(make_rsrc(A_gsb + id, 4), 0, true);
+            if constexpr (MOM) habN = buf_load_f32(make_rsrc(A_m2b + id, 4), 0, true);
         };
 
         bool open_new = true;
@@ -458,17 +528,21 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
         for (int pos = 0; pos < n_valid; ++pos) {
             const int32_t b_id = n_oth, skey = n_key;
             const float w = n_w; const double l = n_l;
-            VT b[NCH], gb[NCH];
+            VT b[NCH], gb[NCH], hb[NCH];
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) { b[q] = nb[q]; gb[q] = ngb[q]; }
-            const float bb = n_bb, gbb = n_gbb;
+            for (int q = 0; q < NCH; ++q) { b[q] = nb[q]; gb[q] = ngb[q]; if constexpr (MOM) hb[q] = nhb[q]; }
+            const float bb = n_bb;
+            float gbb = n_gbb, hbb = n_hbb;
             if (open_new) {
 #pragma unroll
-                for (int q = 0; q < NCH; ++q) { a[q] = aN[q]; ga[q] = gaN[q]; a0[q] = aN[q]; ga0[q] = gaN[q]; }
-                ab = abN; gab = gabN;
+                for (int q = 0; q < NCH; ++q) {
+                    a[q] = aN[q]; ga[q] = gaN[q]; a0[q] = aN[q];
+                    if constexpr (MOM) ha[q] = haN[q]; else ga0[q] = gaN[q];
+                }
+                ab = abN; gab = gabN; hab = habN;
                 cur_id = skey < 0 ? ~skey : skey;
                 cur_hot = res_is_ctx && (p.blocked ? p.hot_enabled != 0 : skey < 0);
-                rs_a = rsN_a; rs_ga = rsN_ga;
+                rs_a = rsN_a; rs_ga = rsN_ga; rs_ha = rsN_ha;
                 run_len = 0;
             }
             const bool last = pos + 1 >= n_valid;
@@ -476,8 +550,8 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             if (!last) {
                 decode(pos + 1);
                 if (n_oth != b_id) request_streamed(); else deferred = true;   // same streamed row twice in a row: re-read after the store
-                // a long hub run is cut every flush_every nonzeros: publish the delta, re-read what the other workers published
-                next_new = n_key != skey || (cur_hot && run_len + 1 >= flush_every);
+                // a long hub run is cut every p.flush_every nonzeros: publish the delta, re-read what the other workers published
+                next_new = n_key != skey || (cur_hot && run_len + 1 >= p.flush_every);
                 if (next_new) request_resident();
             }
             // dot product
@@ -495,31 +569,50 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             const float wlr = wc * lr;
             const __amdgpu_buffer_rsrc_t rb = make_rsrc(B_rows + (int64_t)b_id * D, row_bytes);
             const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)b_id * D, row_bytes);
+            const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)b_id * D, MOM ? row_bytes : 0u);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
                 if (inr[q]) {
-                    VT ob, ogb;
+                    VT ob, ogb, ohb;
 #pragma unroll
                     for (int t = 0; t < VW; ++t) {
                         const float av = comp<VW>(a[q], t), bv = comp<VW>(b[q], t);
-                        const float sa = comp<VW>(ga[q], t), sb = comp<VW>(gb[q], t);
                         const float grad_b = wc * av, grad_a = wc * bv;
-                        comp<VW>(ob, t)    = __builtin_fmaf(-(wlr * av), __frsqrt_rn(sb), bv);
-                        comp<VW>(ogb, t)   = __builtin_fmaf(grad_b, grad_b, sb);
-                        comp<VW>(a[q], t)  = __builtin_fmaf(-(wlr * bv), __frsqrt_rn(sa), av);
-                        comp<VW>(ga[q], t) = __builtin_fmaf(grad_a, grad_a, sa);
+                        if constexpr (!MOM) {
+                            const float sa = comp<VW>(ga[q], t), sb = comp<VW>(gb[q], t);
+                            comp<VW>(ob, t)    = __builtin_fmaf(-(wlr * av), __frsqrt_rn(sb), bv);
+                            comp<VW>(ogb, t)   = __builtin_fmaf(grad_b, grad_b, sb);
+                            comp<VW>(a[q], t)  = __builtin_fmaf(-(wlr * bv), __frsqrt_rn(sa), av);
+                            comp<VW>(ga[q], t) = __builtin_fmaf(grad_a, grad_a, sa);
+                        } else {
+                            float m = comp<VW>(gb[q], t), v = comp<VW>(hb[q], t);
+                            comp<VW>(ob, t) = bv - moment_step(grad_b, m, v);
+                            comp<VW>(ogb, t) = m; comp<VW>(ohb, t) = v;
+                            comp<VW>(a[q], t) = av - moment_step(grad_a, comp<VW>(ga[q], t), comp<VW>(ha[q], t));
+                        }
                     }
                     buf_store<VW>(ob, rb, (lane + q * 64) * VW * 4);
                     buf_store<VW>(ogb, rg, (lane + q * 64) * VW * 4);
+                    if constexpr (MOM) buf_store<VW>(ohb, rh, (lane + q * 64) * VW * 4);
                 }
             }
-            const float w2 = wc * wc;
-            if (lane == 0) {          // no learning rate on the biases (Adagrad.java:88-89)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, bb - wc * __frsqrt_rn(gbb)), make_rsrc(B_bias + b_id, 4), 0, 0, AUX_SC1);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gbb + w2), make_rsrc(B_gsb + b_id, 4), 0, 0, AUX_SC1);
+            if constexpr (!MOM) {
+                const float w2 = wc * wc;
+                if (lane == 0) {          // no learning rate on the biases (Adagrad.java:88-89)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, bb - wc * __frsqrt_rn(gbb)), make_rsrc(B_bias + b_id, 4), 0, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gbb + w2), make_rsrc(B_gsb + b_id, 4), 0, 0, AUX_SC1);
+                }
+                ab = ab - wc * __frsqrt_rn(gab);
+                gab = gab + w2;
+            } else {                      // Adam.java:127-145: the biases take the same moment step with gradient wc
+                const float nbb = bb - moment_step(wc, gbb, hbb);
+                if (lane == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nbb), make_rsrc(B_bias + b_id, 4), 0, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gbb), make_rsrc(B_gsb + b_id, 4), 0, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hbb), make_rsrc(B_m2b + b_id, 4), 0, 0, AUX_SC1);
+                }
+                ab = ab - moment_step(wc, gab, hab);
             }
-            ab = ab - wc * __frsqrt_rn(gab);
-            gab = gab + w2;
             ++run_len;
             if (last || next_new) close_run();
             if (deferred) request_streamed();
@@ -532,21 +625,24 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
 using hogwild_fn = void (*)(GloveParams, int32_t);
 
 
-template <int VW>
+template <int VW, int OPT>
 hogwild_fn pick_nch(int nch) {
     switch (nch) {
-        case 1: return k_adagrad_runs<VW, 1>;
-        case 2: return k_adagrad_runs<VW, 2>;
-        case 3: return k_adagrad_runs<VW, 3>;
-        case 4: return k_adagrad_runs<VW, 4>;
+        case 1: return k_adagrad_runs<VW, 1, OPT>;
+        case 2: return k_adagrad_runs<VW, 2, OPT>;
+        case 3: return k_adagrad_runs<VW, 3, OPT>;
+        case 4: return k_adagrad_runs<VW, 4, OPT>;
         default: return nullptr;
     }
 }
+template <int OPT>
+hogwild_fn pick_vw(int vw, int nch) { return vw == 4 ? pick_nch<4, OPT>(nch) : vw == 2 ? pick_nch<2, OPT>(nch) : pick_nch<1, OPT>(nch); }
 // One wavefront spans a row: 64 lanes x VW floats x NCH chunks >= D.
-hogwild_fn pick_hogwild(int D, int *vw_out, int *nch_out) {
+hogwild_fn pick_hogwild(int D, int opt, int *vw_out, int *nch_out) {
     const int vw = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
     const int nch = (D + 64 * vw - 1) / (64 * vw);
-    hogwild_fn fn = vw == 4 ? pick_nch<4>(nch) : vw == 2 ? pick_nch<2>(nch) : pick_nch<1>(nch);
+    hogwild_fn fn = opt == GE_OPT_ADAGRAD ? pick_vw<GE_OPT_ADAGRAD>(vw, nch)
+                  : opt == GE_OPT_ADAM ? pick_vw<GE_OPT_ADAM>(vw, nch) : pick_vw<GE_OPT_AMSGRAD>(vw, nch);
     *vw_out = vw; *nch_out = nch;
     return fn;
 }
@@ -603,10 +699,18 @@ void fill_params(const ge_glove *h, GloveParams &p, int32_t iteration) {
     p.fbias = h->tab[GE_STATE_FBIAS];     p.cbias = h->tab[GE_STATE_CBIAS];
     p.gsf = h->tab[GE_STATE_GSQ_FOCUS];   p.gsc = h->tab[GE_STATE_GSQ_CONTEXT];
     p.gsfb = h->tab[GE_STATE_GSQ_FBIAS];  p.gscb = h->tab[GE_STATE_GSQ_CBIAS];
+    p.m2f = h->tab[GE_STATE_M2_FOCUS];    p.m2c = h->tab[GE_STATE_M2_CONTEXT];
+    p.m2fb = h->tab[GE_STATE_M2_FBIAS];   p.m2cb = h->tab[GE_STATE_M2_CBIAS];
+    p.opt = h->cfg.opt;
+    {   // Adam.java:84, evaluated in fp64 from the fp32 constants exactly as the Java expression does
+        const float lrf = h->cfg.learning_rate, b1 = 0.9f, b2 = 0.999f;
+        p.correction = (double)lrf * std::sqrt(1 - std::pow((double)b2, (double)(iteration + 1))) / (1 - std::pow((double)b1, (double)(iteration + 1)));
+    }
     // focus-side tables hold rows [row_begin,row_end): rebase so that kernels index by global row id
     const int64_t off = h->cfg.row_begin;
     p.focus -= off * h->cfg.dim;  p.gsf -= off * h->cfg.dim;
     p.fbias -= off;               p.gsfb -= off;
+    if (p.m2f) { p.m2f -= off * h->cfg.dim; p.m2fb -= off; }
     p.I = h->dI; p.J = h->dJ; p.X = h->dX; p.perm = h->dperm; p.L = h->dL; p.W = h->dW;
     p.cost_out = h->dcost;
     p.queue = reinterpret_cast<unsigned long long *>(h->dcost + 1);
@@ -660,7 +764,7 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
         return ge::fail(GE_ERR_ARG, "vocab_size*dim exceeds Java int range (%d x %d)", cfg->vocab_size, cfg->dim);
     if (cfg->nnz > 0 && (!I || !J || !X)) return ge::fail(GE_ERR_ARG, "I/J/X must not be null");
     if (cfg->cost != GE_COST_GLOVE && cfg->cost != GE_COST_PGLOVE) return ge::fail(GE_ERR_ARG, "Invalid cost function %d", cfg->cost);
-    if (cfg->opt != GE_OPT_ADAGRAD) return ge::fail(GE_ERR_ARG, "Invalid optimization method %d (adagrad only)", cfg->opt);
+    if (cfg->opt < GE_OPT_ADAGRAD || cfg->opt > GE_OPT_AMSGRAD) return ge::fail(GE_ERR_ARG, "Invalid optimization method %d", cfg->opt);
     if (cfg->threads < 1) return ge::fail(GE_ERR_ARG, "threads must be >= 1");
     if (cfg->mode != GE_MODE_HOGWILD && cfg->mode != GE_MODE_DETERMINISTIC) return ge::fail(GE_ERR_ARG, "invalid mode %d", cfg->mode);
     if (cfg->shuffle < GE_SHUFFLE_JAVA || cfg->shuffle > GE_SHUFFLE_NONE) return ge::fail(GE_ERR_ARG, "invalid shuffle %d", cfg->shuffle);
@@ -691,11 +795,13 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     GE_TRY(hipGetDeviceProperties(&prop, cfg->device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
+    const bool moments = cfg->opt != GE_OPT_ADAGRAD;      // Adam / AMSGrad keep M2* next to M1*
     const int64_t counts[GE_STATE_COUNT] = {
-        (int64_t)h->rows * D, (int64_t)V * D, h->rows, V, (int64_t)h->rows * D, (int64_t)V * D, h->rows, V};
+        (int64_t)h->rows * D, (int64_t)V * D, h->rows, V, (int64_t)h->rows * D, (int64_t)V * D, h->rows, V,
+        moments ? (int64_t)h->rows * D : 0, moments ? (int64_t)V * D : 0, moments ? h->rows : 0, moments ? V : 0};
     for (int t = 0; t < GE_STATE_COUNT; ++t) {
         h->tab_count[t] = counts[t];
-        GE_TRY(hipMalloc((void **)&h->tab[t], sizeof(float) * (size_t)std::max<int64_t>(counts[t], 1)));
+        if (counts[t] > 0) GE_TRY(hipMalloc((void **)&h->tab[t], sizeof(float) * (size_t)counts[t]));
     }
     const size_t nn = (size_t)std::max<int64_t>(N, 1);
     GE_TRY(hipMalloc((void **)&h->dI, sizeof(int32_t) * nn));
@@ -708,7 +814,7 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     if (cfg->mode == GE_MODE_HOGWILD) {
         if (const char *e = std::getenv("GE_GLOVE_BLOCKS_PER_CU")) h->hw_blocks_per_cu = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("GE_GLOVE_FLUSH_EVERY")) h->flush_every = std::max(1, std::atoi(e));
-        h->hw_fn = pick_hogwild(D, &h->hw_vw, &h->hw_nch);
+        h->hw_fn = pick_hogwild(D, cfg->opt, &h->hw_vw, &h->hw_nch);
         if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 1024 for dim%%4==0, 256 for odd dim)", D); }
         // One wavefront = one sequential worker.  Never more workers than N/2048: a small matrix must
         // not degenerate into one giant stale batch (the JVM has at most #cores updates in flight).
@@ -852,10 +958,12 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
             GE_TRY(hipStreamSynchronize(h->stream));
             (void)hipFree(scr_tab); (void)hipFree(scr_b);
         }
-        for (int t = GE_STATE_GSQ_FOCUS; t <= GE_STATE_GSQ_CBIAS; ++t) {    // Adagrad ctor: gradSq = 1
+        // Adagrad ctor: gradSq = 1 (Adagrad.java:27-33); Adam / AMSGrad ctors: every moment = 0 (new float[])
+        for (int t = GE_STATE_GSQ_FOCUS; t < GE_STATE_COUNT; ++t) {
             const int64_t n = h->tab_count[t];
+            if (n <= 0) continue;
             const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
-            hipLaunchKernelGGL(k_fill, dim3(std::max(blocks, 1)), dim3(256), 0, h->stream, h->tab[t], n, 1.0f);
+            hipLaunchKernelGGL(k_fill, dim3(std::max(blocks, 1)), dim3(256), 0, h->stream, h->tab[t], n, moments ? 0.0f : 1.0f);
         }
     }
     GE_TRY(hipGetLastError());

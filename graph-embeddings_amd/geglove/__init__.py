@@ -9,8 +9,8 @@ All compute goes through libgeglove.so (HIP, gfx950).  Nothing here falls back t
 """
 from . import capi
 from .capi import GeError
-from .host import (Configuration, CooMatrix, BookmarkColoring, Adagrad, Optimum,
+from .host import (Configuration, CooMatrix, BookmarkColoring, Adagrad, Adam, AMSGrad, createOptimizer, Optimum,
                    GloveCost, PGloveCost, InvalidConfigurationException)
 
-__all__ = ["capi", "GeError", "Configuration", "CooMatrix", "BookmarkColoring", "Adagrad", "Optimum",
+__all__ = ["capi", "GeError", "Configuration", "CooMatrix", "BookmarkColoring", "Adagrad", "Adam", "AMSGrad", "createOptimizer", "Optimum",
            "GloveCost", "PGloveCost", "InvalidConfigurationException"]

@@ -12,14 +12,17 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libgeglove.so")
 
 GE_OK, GE_ERR_ARG, GE_ERR_OOM, GE_ERR_HIP, GE_ERR_STATE, GE_ERR_OVERFLOW = 0, -1, -2, -3, -4, -5
 GE_COST_GLOVE, GE_COST_PGLOVE = 0, 1
-GE_OPT_ADAGRAD = 0
+GE_OPT_ADAGRAD, GE_OPT_ADAM, GE_OPT_AMSGRAD = 0, 1, 2
 GE_NORM_NONE, GE_NORM_UNITY, GE_NORM_COUNTS = 0, 1, 2
 GE_MODE_HOGWILD, GE_MODE_DETERMINISTIC = 0, 1
 GE_SHUFFLE_JAVA, GE_SHUFFLE_DEVICE, GE_SHUFFLE_NONE = 0, 1, 2
 GE_HOT_AUTO, GE_HOT_NONE, GE_HOT_ALL = 0, 1, 2
 (GE_STATE_FOCUS, GE_STATE_CONTEXT, GE_STATE_FBIAS, GE_STATE_CBIAS, GE_STATE_GSQ_FOCUS,
- GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FBIAS, GE_STATE_GSQ_CBIAS) = range(8)
+ GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FBIAS, GE_STATE_GSQ_CBIAS, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT,
+ GE_STATE_M2_FBIAS, GE_STATE_M2_CBIAS) = range(12)
 STATE_NAMES = ("focus", "context", "fbias", "cbias", "gsq_focus", "gsq_context", "gsq_fbias", "gsq_cbias")
+M2_NAMES = ("m2_focus", "m2_context", "m2_fbias", "m2_cbias")
+ALL_STATE_NAMES = STATE_NAMES + M2_NAMES
 
 # every symbol include/geglove.h declares (tests check the library exports all of them)
 SYMBOLS = (

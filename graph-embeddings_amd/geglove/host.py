@@ -194,6 +194,8 @@ _SHUFFLES = {"java": capi.GE_SHUFFLE_JAVA, "device": capi.GE_SHUFFLE_DEVICE, "no
 
 
 class Adagrad:
+    OPT = capi.GE_OPT_ADAGRAD
+    NAME = "Adagrad"
     """`new Adagrad(coMatrix, config, costFunction)` + IOptimizer (J/opt/grad/Adagrad.java,
     J/opt/Optimizer.java, J/opt/IOptimizer.java:6-11) over ge_glove_*.
 
@@ -215,7 +217,7 @@ class Adagrad:
         capi.lib().ge_glove_cfg_default(C.byref(cfg))
         cfg.vocab_size, cfg.dim, cfg.nnz = self.vocabSize, self.dimension, self.coCount
         cfg.cost = costFunction.kind
-        cfg.opt = capi.GE_OPT_ADAGRAD
+        cfg.opt = self.OPT
         cfg.learning_rate = float(dev.get("learning_rate", 0.05))
         cfg.xmax = coMatrix.max()
         cfg.seed = int(dev.get("seed", 42))
@@ -237,7 +239,7 @@ class Adagrad:
 
     # -- IOptimizer -----------------------------------------------------------------------
     def getName(self):
-        return "Adagrad"
+        return self.NAME
 
     def epoch(self, iteration=0):
         """One loop body of Optimizer.optimize (shuffle + all jobs); returns the summed job cost."""
@@ -282,14 +284,14 @@ class Adagrad:
     # -- state access (tests / multi-GPU sync) ---------------------------------------------------
     def _count(self, which):
         rows = self._rows if which in (capi.GE_STATE_FOCUS, capi.GE_STATE_FBIAS, capi.GE_STATE_GSQ_FOCUS,
-                                       capi.GE_STATE_GSQ_FBIAS) else self.vocabSize
+                                       capi.GE_STATE_GSQ_FBIAS, capi.GE_STATE_M2_FOCUS, capi.GE_STATE_M2_FBIAS) else self.vocabSize
         per_row = self.dimension if which in (capi.GE_STATE_FOCUS, capi.GE_STATE_CONTEXT, capi.GE_STATE_GSQ_FOCUS,
-                                              capi.GE_STATE_GSQ_CONTEXT) else 1
+                                              capi.GE_STATE_GSQ_CONTEXT, capi.GE_STATE_M2_FOCUS, capi.GE_STATE_M2_CONTEXT) else 1
         return rows * per_row
 
     def get_state(self, which):
         if isinstance(which, str):
-            which = capi.STATE_NAMES.index(which)
+            which = capi.ALL_STATE_NAMES.index(which)
         n = self._count(which)
         out = np.empty(n, np.float32)
         capi.check(capi.lib().ge_glove_get_state(self._h, which, _p(out, C.c_float), n))
@@ -297,16 +299,17 @@ class Adagrad:
 
     def set_state(self, which, arr):
         if isinstance(which, str):
-            which = capi.STATE_NAMES.index(which)
+            which = capi.ALL_STATE_NAMES.index(which)
         arr = np.ascontiguousarray(arr, np.float32).reshape(-1)
         capi.check(capi.lib().ge_glove_set_state(self._h, which, _p(arr, C.c_float), arr.shape[0]))
 
     def state(self):
-        return {n: self.get_state(i) for i, n in enumerate(capi.STATE_NAMES)}
+        names = capi.STATE_NAMES if self.OPT == capi.GE_OPT_ADAGRAD else capi.ALL_STATE_NAMES
+        return {n: self.get_state(i) for i, n in enumerate(names)}
 
     def device_ptr(self, which):
         if isinstance(which, str):
-            which = capi.STATE_NAMES.index(which)
+            which = capi.ALL_STATE_NAMES.index(which)
         p = C.c_void_p(); n = C.c_int64()
         capi.check(capi.lib().ge_glove_device_ptr(self._h, which, C.byref(p), C.byref(n)))
         return p.value, n.value
@@ -347,3 +350,28 @@ class Adagrad:
             self.close()
         except Exception:
             pass
+
+
+class Adam(Adagrad):
+    """`new Adam(coMatrix, config, costFunction)` (J/opt/grad/Adam.java)"""
+    OPT = capi.GE_OPT_ADAM
+    NAME = "Adam"
+
+
+class AMSGrad(Adagrad):
+    """`new AMSGrad(coMatrix, config, costFunction)` (J/opt/grad/AMSGrad.java)"""
+    OPT = capi.GE_OPT_AMSGRAD
+    NAME = "AMSGrad"
+
+
+def createOptimizer(config, coMatrix, **kw):
+    """Main.createOptimizer (J/Main.java:107-131)."""
+    cf = config.costFunction()
+    m = str(config.getOptMethod()).upper()
+    if m == "ADAGRAD":
+        return Adagrad(coMatrix, config, cf, **kw)
+    if m == "ADAM":
+        return Adam(coMatrix, config, cf, **kw)
+    if m == "AMSGRAD":
+        return AMSGrad(coMatrix, config, cf, **kw)
+    raise ValueError("Invalid optimization method")

@@ -578,11 +578,13 @@ enum class CostFunction { GLOVE, PGLOVE };       // GloveCost / PGloveCost
 
 class Adagrad : public IOptimizer {              // J/opt/grad/Adagrad.java + J/opt/Optimizer.java
 public:
-    Adagrad(const CoOccurrenceMatrix &m, const Configuration &config, CostFunction cf, void (*progress)(int, double, double) = nullptr)
+    Adagrad(const CoOccurrenceMatrix &m, const Configuration &config, CostFunction cf, void (*progress)(int, double, double) = nullptr,
+            int opt = GE_OPT_ADAGRAD, const char *name = "Adagrad")
         : coCount_(m.coOccurrenceCount()), vocab_(m.vocabSize()), dim_(config.dim), maxIter_(config.opt.maxiter),
-          tolerance_(config.opt.tolerance), progress_(progress) {
+          tolerance_(config.opt.tolerance), progress_(progress), name_(name) {
         ge_glove_cfg cfg;
         ge_glove_cfg_default(&cfg);
+        cfg.opt = opt;
         cfg.vocab_size = vocab_; cfg.dim = dim_; cfg.nnz = coCount_;
         cfg.cost = cf == CostFunction::GLOVE ? GE_COST_GLOVE : GE_COST_PGLOVE;
         cfg.xmax = m.max();
@@ -598,7 +600,7 @@ public:
         check(ge_glove_create(&cfg, m.dataI(), m.dataJ(), m.dataX(), &h));
         h_.reset(h);
     }
-    std::string getName() const override { return "Adagrad"; }
+    std::string getName() const override { return name_; }
     Optimum optimize() override {                 // Optimizer.optimize, J/opt/Optimizer.java:66-120
         Optimum opt;
         double finalCost = 0, prevCost = 0;
@@ -627,6 +629,14 @@ private:
     int coCount_, vocab_, dim_, maxIter_;
     double tolerance_;
     void (*progress_)(int, double, double);
+    std::string name_;
+};
+// `new Adam(...)` / `new AMSGrad(...)` (J/opt/grad/Adam.java, AMSGrad.java): same driver, other update rule in the library
+struct Adam : Adagrad {
+    Adam(const CoOccurrenceMatrix &m, const Configuration &c, CostFunction cf, void (*pr)(int, double, double) = nullptr) : Adagrad(m, c, cf, pr, GE_OPT_ADAM, "Adam") {}
+};
+struct AMSGrad : Adagrad {
+    AMSGrad(const CoOccurrenceMatrix &m, const Configuration &c, CostFunction cf, void (*pr)(int, double, double) = nullptr) : Adagrad(m, c, cf, pr, GE_OPT_AMSGRAD, "AMSGrad") {}
 };
 
 // Main.createOptimizer (J/Main.java:107-131)
@@ -638,7 +648,8 @@ inline std::unique_ptr<IOptimizer> createOptimizer(const Configuration &config, 
     else throw std::invalid_argument("Invalid cost function");
     std::string om = config.opt.method; for (auto &ch : om) ch = (char)std::toupper((unsigned char)ch);
     if (om == "ADAGRAD") return std::unique_ptr<IOptimizer>(new Adagrad(m, config, cf, progress));
-    if (om == "ADAM" || om == "AMSGRAD") throw std::invalid_argument("optimization method " + config.opt.method + " is not available in the device library yet (adagrad only)");
+    if (om == "ADAM") return std::unique_ptr<IOptimizer>(new Adam(m, config, cf, progress));
+    if (om == "AMSGRAD") return std::unique_ptr<IOptimizer>(new AMSGrad(m, config, cf, progress));
     throw std::invalid_argument("Invalid optimization method");
 }
 

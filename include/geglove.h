@@ -38,8 +38,9 @@ enum {
  * GloveCost (J/opt/GloveCost.java:5-21) or PGloveCost (J/opt/PGloveCost.java:5-21). */
 enum { GE_COST_GLOVE = 0, GE_COST_PGLOVE = 1 };
 /* Configuration.OptimizationMethod (J/util/config/Configuration.java:23-25); Main.createOptimizer
- * (J/Main.java:121-130).  Only ADAGRAD is implemented this round. */
-enum { GE_OPT_ADAGRAD = 0 };
+ * (J/Main.java:121-130): Adagrad (J/opt/grad/Adagrad.java), Adam (J/opt/grad/Adam.java:75-147),
+ * AMSGrad (J/opt/grad/AMSGrad.java:91-162).  beta1 = 0.9f, beta2 = 0.999f, epsilon = 1e-7f as hard coded there. */
+enum { GE_OPT_ADAGRAD = 0, GE_OPT_ADAM = 1, GE_OPT_AMSGRAD = 2 };
 /* Configuration.BCANormalization (J/util/config/Configuration.java:31-33). */
 enum { GE_NORM_NONE = 0, GE_NORM_UNITY = 1, GE_NORM_COUNTS = 2 };
 
@@ -81,11 +82,15 @@ enum {
     GE_STATE_CONTEXT = 1,      /* float[V*D]  Optimizer.context                                  */
     GE_STATE_FBIAS = 2,        /* float[V]    Optimizer.fBias         (J/opt/Optimizer.java:28) */
     GE_STATE_CBIAS = 3,        /* float[V]    Optimizer.cBias                                    */
-    GE_STATE_GSQ_FOCUS = 4,    /* float[V*D]  Adagrad.gradSqFocus     (J/opt/grad/Adagrad.java:16) */
-    GE_STATE_GSQ_CONTEXT = 5,  /* float[V*D]  Adagrad.gradSqContext                              */
-    GE_STATE_GSQ_FBIAS = 6,    /* float[V]    Adagrad.gradSqFBias     (J/opt/grad/Adagrad.java:17) */
-    GE_STATE_GSQ_CBIAS = 7,    /* float[V]    Adagrad.gradSqCBias                                */
-    GE_STATE_COUNT = 8
+    GE_STATE_GSQ_FOCUS = 4,    /* float[V*D]  Adagrad.gradSqFocus     (J/opt/grad/Adagrad.java:16) | Adam/AMSGrad.M1focus   */
+    GE_STATE_GSQ_CONTEXT = 5,  /* float[V*D]  Adagrad.gradSqContext                                | Adam/AMSGrad.M1context */
+    GE_STATE_GSQ_FBIAS = 6,    /* float[V]    Adagrad.gradSqFBias     (J/opt/grad/Adagrad.java:17) | Adam/AMSGrad.M1fBias   */
+    GE_STATE_GSQ_CBIAS = 7,    /* float[V]    Adagrad.gradSqCBias                                  | Adam/AMSGrad.M1cBias   */
+    GE_STATE_M2_FOCUS = 8,     /* float[V*D]  Adam/AMSGrad.M2focus    (J/opt/grad/Adam.java:40-41); empty for Adagrad */
+    GE_STATE_M2_CONTEXT = 9,   /* float[V*D]  Adam/AMSGrad.M2context */
+    GE_STATE_M2_FBIAS = 10,    /* float[V]    Adam/AMSGrad.M2fBias   */
+    GE_STATE_M2_CBIAS = 11,    /* float[V]    Adam/AMSGrad.M2cBias   */
+    GE_STATE_COUNT = 12
 };
 
 /* ------------------------------------------------------------------------------------------

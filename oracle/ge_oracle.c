@@ -441,9 +441,12 @@ struct geo_glove {
     int32_t V, D; int64_t N; int threads; int cost_kind; double xmax;
     int32_t *I, *J; float *X;
     float *focus, *context, *fbias, *cbias;
-    float *gsf, *gsc, *gsfb, *gscb;
+    float *gsf, *gsc, *gsfb, *gscb;      /* Adagrad.gradSq*  or  Adam/AMSGrad.M1* */
+    float *m2f, *m2c, *m2fb, *m2cb;      /* Adam/AMSGrad.M2* (unused by Adagrad)  */
     int32_t *perm;
     geo_jrand rng;
+    int opt_kind;
+    int iteration;                       /* argument of createJob(id, iteration) for the next epoch */
 };
 
 static const float LEARNING_RATE = 0.05f;     /* J/opt/Optimizer.java:26 */
@@ -489,6 +492,83 @@ static inline void adagrad_update(int kind, double xmax, int32_t D, int32_t bu, 
     gscb[bv] += wc;                                                        /* :93 */
 }
 
+/* FastMath.max(float,float) of commons-math 2.x */
+static inline float fastmath_maxf(float a, float b) { return (a <= b) ? b : ((a + b) != (a + b) ? NAN : a); }
+
+static const float ADAM_BETA1 = 0.9f, ADAM_BETA2 = 0.999f, ADAM_EPS = 1e-7f;    /* J/opt/grad/Adam.java:45-53 */
+
+/* Adam.createJob's per-job constant  J/opt/grad/Adam.java:84 */
+static double adam_correction(int iteration) {
+    return LEARNING_RATE * sqrt(1 - pow(ADAM_BETA2, iteration + 1)) / (1 - pow(ADAM_BETA1, iteration + 1));
+}
+
+/* Adam.createJob body (J/opt/grad/Adam.java:86-146) and AMSGrad.createJob body (J/opt/grad/AMSGrad.java:100-160)
+ * for one nonzero.  m1* live in the gs* arrays of the shared state, m2* in the m2* arrays. */
+static inline void adam_update(int ams, double correction, int kind, double xmax, int32_t D, int32_t bu, int32_t bv, float Xij,
+                               float *focus, float *context, float *fbias, float *cbias,
+                               float *M1f, float *M1c, float *M1fb, float *M1cb,
+                               float *M2f, float *M2c, float *M2fb, float *M2cb, float *cost) {
+    float *foc = focus + (int64_t)bu * D, *ctx = context + (int64_t)bv * D;
+    float *m1f = M1f + (int64_t)bu * D, *m1c = M1c + (int64_t)bv * D;
+    float *m2f = M2f + (int64_t)bu * D, *m2c = M2c + (int64_t)bv * D;
+    const float beta1 = ADAM_BETA1, beta2 = ADAM_BETA2, epsilon = ADAM_EPS;
+    const float ic = inner_cost(kind, D, foc, ctx, fbias[bu], cbias[bv], Xij);
+    const float wc = weighted_cost(kind, xmax, ic, Xij);
+    *cost = (float)((double)*cost + 0.5 * wc * ic);
+    for (int32_t d = 0; d < D; d++) {
+        const float grad_u = wc * ctx[d];
+        const float grad_v = wc * foc[d];
+        const float m1 = beta1 * m1f[d] + (1 - beta1) * grad_u;
+        const float m2 = beta1 * m1c[d] + (1 - beta1) * grad_v;
+        float v1, v2;
+        if (!ams) {
+            v1 = beta2 * m2f[d] + (1 - beta2) * (grad_u * grad_u);
+            v2 = beta2 * m2c[d] + (1 - beta2) * (grad_v * grad_v);
+            foc[d] = (float)((double)foc[d] - correction * m1 / (sqrt((double)v1) + epsilon));      /* Adam.java:118 */
+            ctx[d] = (float)((double)ctx[d] - correction * m2 / (sqrt((double)v2) + epsilon));
+        } else {
+            v1 = fastmath_maxf(m2f[d], beta2 * m2f[d] + (1 - beta2) * (grad_u * grad_u));          /* AMSGrad.java:129-130 */
+            v2 = fastmath_maxf(m2c[d], beta2 * m2c[d] + (1 - beta2) * (grad_v * grad_v));
+            foc[d] = (float)((double)foc[d] - LEARNING_RATE / (sqrt((double)v1) + epsilon) * m1);   /* AMSGrad.java:133 */
+            ctx[d] = (float)((double)ctx[d] - LEARNING_RATE / (sqrt((double)v2) + epsilon) * m2);
+        }
+        m1f[d] = m1; m1c[d] = m2; m2f[d] = v1; m2c[d] = v2;
+    }
+    const float m1 = beta1 * M1fb[bu] + (1 - beta1) * wc;
+    const float m2 = beta1 * M1cb[bv] + (1 - beta1) * wc;
+    float v1, v2;
+    if (!ams) {
+        v1 = beta2 * M2fb[bu] + (1 - beta2) * (wc * wc);
+        v2 = beta2 * M2cb[bv] + (1 - beta2) * (wc * wc);
+        fbias[bu] = (float)((double)fbias[bu] - correction * m1 / (sqrt((double)v1) + epsilon));
+        cbias[bv] = (float)((double)cbias[bv] - correction * m2 / (sqrt((double)v2) + epsilon));
+    } else {
+        v1 = fastmath_maxf(M2fb[bu], beta2 * M2fb[bu] + (1 - beta2) * (wc * wc));
+        v2 = fastmath_maxf(M2cb[bv], beta2 * M2cb[bv] + (1 - beta2) * (wc * wc));
+        fbias[bu] = (float)((double)fbias[bu] - LEARNING_RATE / (sqrt((double)v1) + epsilon) * m1);
+        cbias[bv] = (float)((double)cbias[bv] - LEARNING_RATE / (sqrt((double)v2) + epsilon) * m2);
+    }
+    M1fb[bu] = m1; M1cb[bv] = m2; M2fb[bu] = v1; M2cb[bv] = v2;
+}
+
+float geo_opt_job(int opt_kind, int iteration, int32_t D, int64_t n, const int32_t *I, const int32_t *J, const float *X,
+                  double xmax, int cost_kind,
+                  float *focus, float *context, float *fbias, float *cbias,
+                  float *s1f, float *s1c, float *s1fb, float *s1cb,
+                  float *s2f, float *s2c, float *s2fb, float *s2cb) {
+    float cost = 0;
+    if (opt_kind == GEO_OPT_ADAGRAD) {
+        for (int64_t k = 0; k < n; k++)
+            adagrad_update(cost_kind, xmax, D, I[k], J[k], X[k], focus, context, fbias, cbias, s1f, s1c, s1fb, s1cb, &cost);
+    } else {
+        const double correction = adam_correction(iteration);
+        for (int64_t k = 0; k < n; k++)
+            adam_update(opt_kind == GEO_OPT_AMSGRAD, correction, cost_kind, xmax, D, I[k], J[k], X[k], focus, context, fbias, cbias,
+                        s1f, s1c, s1fb, s1cb, s2f, s2c, s2fb, s2cb, &cost);
+    }
+    return cost;
+}
+
 float geo_adagrad_job(int32_t D, int64_t n, const int32_t *I, const int32_t *J, const float *X,
                       double xmax, int cost_kind,
                       float *focus, float *context, float *fbias, float *cbias,
@@ -503,8 +583,15 @@ float geo_adagrad_job(int32_t D, int64_t n, const int32_t *I, const int32_t *J, 
 geo_glove *geo_glove_create(int32_t V, int32_t D, int64_t N,
                             const int32_t *I, const int32_t *J, const float *X,
                             double xmax, int cost_kind, int64_t seed, int threads) {
+    return geo_glove_create_opt(V, D, N, I, J, X, xmax, cost_kind, seed, threads, GEO_OPT_ADAGRAD);
+}
+
+geo_glove *geo_glove_create_opt(int32_t V, int32_t D, int64_t N,
+                            const int32_t *I, const int32_t *J, const float *X,
+                            double xmax, int cost_kind, int64_t seed, int threads, int opt_kind) {
     geo_glove *g = (geo_glove *)calloc(1, sizeof(*g));
     if (!g) return NULL;
+    g->opt_kind = opt_kind;
     g->V = V; g->D = D; g->N = N; g->threads = threads < 1 ? 1 : threads;
     g->cost_kind = cost_kind; g->xmax = xmax;
     size_t vd = (size_t)V * (size_t)D;
@@ -520,6 +607,10 @@ geo_glove *geo_glove_create(int32_t V, int32_t D, int64_t N,
     g->cbias = (float *)malloc(sizeof(float) * (size_t)(V ? V : 1));
     g->gsfb = (float *)malloc(sizeof(float) * (size_t)(V ? V : 1));
     g->gscb = (float *)malloc(sizeof(float) * (size_t)(V ? V : 1));
+    g->m2f = (float *)calloc((vd ? vd : 1), sizeof(float));
+    g->m2c = (float *)calloc((vd ? vd : 1), sizeof(float));
+    g->m2fb = (float *)calloc((size_t)(V ? V : 1), sizeof(float));
+    g->m2cb = (float *)calloc((size_t)(V ? V : 1), sizeof(float));
     memcpy(g->I, I, sizeof(int32_t) * (size_t)N);
     memcpy(g->J, J, sizeof(int32_t) * (size_t)N);
     memcpy(g->X, X, sizeof(float) * (size_t)N);
@@ -533,9 +624,10 @@ geo_glove *geo_glove_create(int32_t V, int32_t D, int64_t N,
             g->context[(size_t)i * D + d] = (float)(geo_jrand_next_float(&g->rng) - 0.5) / D;
         }
     }
-    /* Adagrad ctor  J/opt/grad/Adagrad.java:27-33 */
-    for (size_t k = 0; k < vd; k++) g->gsf[k] = g->gsc[k] = 1;
-    for (int32_t i = 0; i < V; i++) g->gsfb[i] = g->gscb[i] = 1;
+    /* Adagrad ctor  J/opt/grad/Adagrad.java:27-33: gradSq = 1;  Adam / AMSGrad ctors: moments = 0 (new float[]) */
+    const float init1 = opt_kind == GEO_OPT_ADAGRAD ? 1.0f : 0.0f;
+    for (size_t k = 0; k < vd; k++) g->gsf[k] = g->gsc[k] = init1;
+    for (int32_t i = 0; i < V; i++) g->gsfb[i] = g->gscb[i] = init1;
     /* Permutation ctor  J/util/rnd/Permutation.java:11-15 */
     for (int64_t k = 0; k < N; k++) g->perm[k] = (int32_t)k;
     return g;
@@ -546,6 +638,7 @@ void geo_glove_destroy(geo_glove *g) {
     free(g->I); free(g->J); free(g->X); free(g->perm);
     free(g->focus); free(g->context); free(g->gsf); free(g->gsc);
     free(g->fbias); free(g->cbias); free(g->gsfb); free(g->gscb);
+    free(g->m2f); free(g->m2c); free(g->m2fb); free(g->m2cb);
     free(g);
 }
 
@@ -560,10 +653,16 @@ static void *run_job(void *p) {
     const int64_t offset = per * a->id;                                   /* :47 */
     const int64_t lines = (a->id == T - 1) ? per + g->N % T : per;        /* Optimizer.java:59-63 */
     float cost = 0;
+    const double correction = adam_correction(g->iteration);
     for (int64_t i = 0; i < lines; i++) {
         const int32_t p2 = g->perm[i + offset];                           /* BookmarkColoring.java:127-137 */
-        adagrad_update(g->cost_kind, g->xmax, g->D, g->I[p2], g->J[p2], g->X[p2],
-                       g->focus, g->context, g->fbias, g->cbias, g->gsf, g->gsc, g->gsfb, g->gscb, &cost);
+        if (g->opt_kind == GEO_OPT_ADAGRAD)
+            adagrad_update(g->cost_kind, g->xmax, g->D, g->I[p2], g->J[p2], g->X[p2],
+                           g->focus, g->context, g->fbias, g->cbias, g->gsf, g->gsc, g->gsfb, g->gscb, &cost);
+        else
+            adam_update(g->opt_kind == GEO_OPT_AMSGRAD, correction, g->cost_kind, g->xmax, g->D, g->I[p2], g->J[p2], g->X[p2],
+                        g->focus, g->context, g->fbias, g->cbias, g->gsf, g->gsc, g->gsfb, g->gscb,
+                        g->m2f, g->m2c, g->m2fb, g->m2cb, &cost);
     }
     a->cost = cost;
     return NULL;
@@ -582,6 +681,7 @@ double geo_glove_epoch_noshuffle(geo_glove *g, int race) {
         for (int t = 0; t < T; t++) { args[t].g = g; args[t].id = t; run_job(&args[t]); local += args[t].cost; }
     }
     free(args);
+    g->iteration++;
     return g->N ? local / (double)g->N : local / 0.0;                     /* Optimizer.java:96 */
 }
 
@@ -619,6 +719,11 @@ float   *geo_glove_gsq_focus(geo_glove *g)   { return g->gsf; }
 float   *geo_glove_gsq_context(geo_glove *g) { return g->gsc; }
 float   *geo_glove_gsq_fbias(geo_glove *g)   { return g->gsfb; }
 float   *geo_glove_gsq_cbias(geo_glove *g)   { return g->gscb; }
+float   *geo_glove_m2_focus(geo_glove *g)    { return g->m2f; }
+float   *geo_glove_m2_context(geo_glove *g)  { return g->m2c; }
+float   *geo_glove_m2_fbias(geo_glove *g)    { return g->m2fb; }
+float   *geo_glove_m2_cbias(geo_glove *g)    { return g->m2cb; }
+void     geo_glove_set_iteration(geo_glove *g, int it) { g->iteration = it; }
 int32_t *geo_glove_perm(geo_glove *g)        { return g->perm; }
 uint64_t geo_glove_rng_state(const geo_glove *g) { return g->rng.seed; }
 

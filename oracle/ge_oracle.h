@@ -68,6 +68,8 @@ int64_t geo_bca_single(int32_t V,
 
 /* ---- GloVe / pGloVe AdaGrad trainer (J/opt/Optimizer.java, J/opt/grad/Adagrad.java) ---- */
 enum { GEO_COST_GLOVE = 0, GEO_COST_PGLOVE = 1 };
+/* Configuration.OptimizationMethod: Adagrad (J/opt/grad/Adagrad.java), Adam (Adam.java), AMSGrad (AMSGrad.java) */
+enum { GEO_OPT_ADAGRAD = 0, GEO_OPT_ADAM = 1, GEO_OPT_AMSGRAD = 2 };
 
 typedef struct geo_glove geo_glove;
 
@@ -79,6 +81,11 @@ typedef struct geo_glove geo_glove;
 geo_glove *geo_glove_create(int32_t V, int32_t D, int64_t N,
                             const int32_t *I, const int32_t *J, const float *X,
                             double xmax, int cost_kind, int64_t seed, int threads);
+/* Same for `new Adam(...)` / `new AMSGrad(...)` (J/Main.java:126-129): moments start at 0.  In the shared
+ * state the first-moment tables M1* take the place of gradSq*, the second moments are the m2_* tables. */
+geo_glove *geo_glove_create_opt(int32_t V, int32_t D, int64_t N,
+                            const int32_t *I, const int32_t *J, const float *X,
+                            double xmax, int cost_kind, int64_t seed, int threads, int opt_kind);
 void   geo_glove_destroy(geo_glove *g);
 /* One iteration of Optimizer.optimize()'s loop body (J/opt/Optimizer.java:79-96):
  * shuffle (cumulative Fisher-Yates), T jobs, returns localCost = sum/N.
@@ -101,6 +108,11 @@ float   *geo_glove_gsq_focus(geo_glove *g);
 float   *geo_glove_gsq_context(geo_glove *g);
 float   *geo_glove_gsq_fbias(geo_glove *g);
 float   *geo_glove_gsq_cbias(geo_glove *g);
+float   *geo_glove_m2_focus(geo_glove *g);
+float   *geo_glove_m2_context(geo_glove *g);
+float   *geo_glove_m2_fbias(geo_glove *g);
+float   *geo_glove_m2_cbias(geo_glove *g);
+void     geo_glove_set_iteration(geo_glove *g, int iteration);
 int32_t *geo_glove_perm(geo_glove *g);
 uint64_t geo_glove_rng_state(const geo_glove *g);
 
@@ -112,6 +124,14 @@ float geo_adagrad_job(int32_t D, int64_t n,
                       double xmax, int cost_kind,
                       float *focus, float *context, float *fbias, float *cbias,
                       float *gsf, float *gsc, float *gsfb, float *gscb);
+
+/* One job of any optimiser over (I,J,X) in the given order on caller-owned state; `iteration` is createJob's
+ * argument (Adam's bias correction).  s1* = gradSq (Adagrad) or M1 (Adam/AMSGrad); s2* = M2 (ignored by Adagrad). */
+float geo_opt_job(int opt_kind, int iteration, int32_t D, int64_t n,
+                  const int32_t *I, const int32_t *J, const float *X, double xmax, int cost_kind,
+                  float *focus, float *context, float *fbias, float *cbias,
+                  float *s1f, float *s1c, float *s1fb, float *s1cb,
+                  float *s2f, float *s2c, float *s2fb, float *s2cb);
 
 /* String.format("%11.6E", v) (J/util/write/EmbeddingTextWriter.java:134):
  * Java rounds HALF_UP on the shortest-repr decimal of the double. */

@@ -15,6 +15,9 @@ _LIB_PATH = os.path.join(_HERE, "libge_oracle.so")
 
 NORM_NONE, NORM_UNITY, NORM_COUNTS = 0, 1, 2
 COST_GLOVE, COST_PGLOVE = 0, 1
+OPT_ADAGRAD, OPT_ADAM, OPT_AMSGRAD = 0, 1, 2
+STATE_NAMES = ("focus", "context", "fbias", "cbias", "gsq_focus", "gsq_context", "gsq_fbias", "gsq_cbias",
+               "m2_focus", "m2_context", "m2_fbias", "m2_cbias")
 
 
 def build(force=False):
@@ -52,13 +55,19 @@ def lib():
     L.geo_glove_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, i32p, i32p, f32p,
                                    C.c_double, C.c_int, C.c_int64, C.c_int]
     L.geo_glove_create.restype = C.c_void_p
+    L.geo_glove_create_opt.argtypes = [C.c_int32, C.c_int32, C.c_int64, i32p, i32p, f32p,
+                                       C.c_double, C.c_int, C.c_int64, C.c_int, C.c_int]
+    L.geo_glove_create_opt.restype = C.c_void_p
+    L.geo_glove_set_iteration.argtypes = [C.c_void_p, C.c_int]
+    L.geo_opt_job.argtypes = [C.c_int, C.c_int, C.c_int32, C.c_int64, i32p, i32p, f32p, C.c_double, C.c_int] + [f32p] * 12
+    L.geo_opt_job.restype = C.c_float
     L.geo_glove_destroy.argtypes = [C.c_void_p]
     L.geo_glove_epoch.argtypes = [C.c_void_p, C.c_int]; L.geo_glove_epoch.restype = C.c_double
     L.geo_glove_epoch_noshuffle.argtypes = [C.c_void_p, C.c_int]; L.geo_glove_epoch_noshuffle.restype = C.c_double
     L.geo_glove_optimize.argtypes = [C.c_void_p, C.c_int, C.c_double, f64p, f64p, C.c_int]
     L.geo_glove_optimize.restype = C.c_int
     L.geo_glove_extract.argtypes = [C.c_void_p, f64p]
-    for nm in ("focus", "context", "fbias", "cbias", "gsq_focus", "gsq_context", "gsq_fbias", "gsq_cbias"):
+    for nm in STATE_NAMES:
         f = getattr(L, "geo_glove_" + nm); f.argtypes = [C.c_void_p]; f.restype = f32p
     L.geo_glove_perm.argtypes = [C.c_void_p]; L.geo_glove_perm.restype = i32p
     L.geo_glove_rng_state.argtypes = [C.c_void_p]; L.geo_glove_rng_state.restype = C.c_uint64
@@ -148,12 +157,13 @@ def bca_single(V, out_csr, in_csr, alpha, epsilon, bookmark, directed=True, norm
 class Glove:
     """Adagrad optimizer restatement (Optimizer + Adagrad + Glove/PGloveCost)."""
 
-    def __init__(self, V, D, I, J, X, xmax, cost=COST_GLOVE, seed=42, threads=1):
+    def __init__(self, V, D, I, J, X, xmax, cost=COST_GLOVE, seed=42, threads=1, opt=OPT_ADAGRAD):
         I = np.ascontiguousarray(I, np.int32); J = np.ascontiguousarray(J, np.int32)
         X = np.ascontiguousarray(X, np.float32)
         self.V, self.D, self.N = V, D, len(I)
-        self._h = lib().geo_glove_create(V, D, self.N, _p(I, C.c_int32), _p(J, C.c_int32), _p(X, C.c_float),
-                                         float(xmax), cost, seed, threads)
+        self.opt = opt
+        self._h = lib().geo_glove_create_opt(V, D, self.N, _p(I, C.c_int32), _p(J, C.c_int32), _p(X, C.c_float),
+                                             float(xmax), cost, seed, threads, opt)
         if not self._h:
             raise MemoryError
 
@@ -200,15 +210,25 @@ class Glove:
     @property
     def gsq_cbias(self): return self._arr("gsq_cbias", self.V)
     @property
+    def m2_focus(self): return self._arr("m2_focus", self.V * self.D).reshape(self.V, self.D)
+    @property
+    def m2_context(self): return self._arr("m2_context", self.V * self.D).reshape(self.V, self.D)
+    @property
+    def m2_fbias(self): return self._arr("m2_fbias", self.V)
+    @property
+    def m2_cbias(self): return self._arr("m2_cbias", self.V)
+    @property
     def perm(self): return self._arr("perm", self.N)
     @property
     def rng_state(self): return lib().geo_glove_rng_state(self._h)
 
-    def state(self):
-        return dict(focus=self.focus.copy(), context=self.context.copy(), fbias=self.fbias.copy(),
-                    cbias=self.cbias.copy(), gsq_focus=self.gsq_focus.copy(),
-                    gsq_context=self.gsq_context.copy(), gsq_fbias=self.gsq_fbias.copy(),
-                    gsq_cbias=self.gsq_cbias.copy())
+    def state(self, full=None):
+        """Copy of the tables; the m2_* tables are included for Adam/AMSGrad (or with full=True)."""
+        names = STATE_NAMES if (full if full is not None else self.opt != OPT_ADAGRAD) else STATE_NAMES[:8]
+        return {n: getattr(self, n).copy() for n in names}
+
+    def set_iteration(self, it):
+        lib().geo_glove_set_iteration(self._h, it)
 
 
 def adagrad_job(D, I, J, X, xmax, cost, state):
@@ -220,6 +240,16 @@ def adagrad_job(D, I, J, X, xmax, cost, state):
         assert state[k].dtype == np.float32 and state[k].flags.c_contiguous
     return lib().geo_adagrad_job(D, len(I), _p(I, C.c_int32), _p(J, C.c_int32), _p(X, C.c_float),
                                  float(xmax), cost, *[_p(state[k], C.c_float) for k in names])
+
+
+def opt_job(opt, iteration, D, I, J, X, xmax, cost, state):
+    """One job of Adagrad / Adam / AMSGrad over (I,J,X) in the given order on a 12-table state dict (in place)."""
+    I = np.ascontiguousarray(I, np.int32); J = np.ascontiguousarray(J, np.int32)
+    X = np.ascontiguousarray(X, np.float32)
+    for k in STATE_NAMES:
+        assert state[k].dtype == np.float32 and state[k].flags.c_contiguous, k
+    return lib().geo_opt_job(opt, iteration, D, len(I), _p(I, C.c_int32), _p(J, C.c_int32), _p(X, C.c_float),
+                             float(xmax), cost, *[_p(state[k], C.c_float) for k in STATE_NAMES])
 
 
 def format_11_6E(v):

@@ -6,11 +6,11 @@ from geglove import capi
 import oracle as O
 
 
-def make_config(dim, method="glove", threads=1, maxiter=5, tolerance=0.0, **device):
+def make_config(dim, method="glove", threads=1, maxiter=5, tolerance=0.0, opt="adagrad", **device):
     return geglove.Configuration({
         "graph": "synthetic", "method": method, "dim": dim, "threads": threads,
         "bca": {"alpha": 0.1, "epsilon": 1e-3, "directed": True},
-        "opt": {"method": "adagrad", "tolerance": tolerance, "maxiter": maxiter},
+        "opt": {"method": opt, "tolerance": tolerance, "maxiter": maxiter},
         "output": {"uri": []}, "device": device})
 
 
@@ -18,9 +18,12 @@ def cost_kind(method):
     return O.COST_GLOVE if method == "glove" else O.COST_PGLOVE
 
 
+OPT_KIND = {"adagrad": O.OPT_ADAGRAD, "adam": O.OPT_ADAM, "amsgrad": O.OPT_AMSGRAD}
+
+
 def assert_state_equal(dev_state, ora, exact=True, rtol=0.0, atol=0.0, what=""):
     ora_state = ora.state() if hasattr(ora, "state") else ora
-    for name in capi.STATE_NAMES:
+    for name in dev_state:
         a = np.asarray(dev_state[name]).reshape(-1)
         b = np.asarray(ora_state[name]).reshape(-1)
         assert a.shape == b.shape, (name, a.shape, b.shape)

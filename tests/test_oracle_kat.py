@@ -281,3 +281,54 @@ def test_format_11_6E_half_up():
     assert O.format_11_6E(0.12345675) == "1.234568E-01"        # HALF_UP on the shortest repr (C would give ...67)
     assert O.format_11_6E(9.9999999e-5) == "1.000000E-04"
     assert O.format_11_6E(1.0) == "1.000000E+00"
+
+
+def py_adam_update(ams, iteration, kind, xmax, D, st, bu, bv, X, cost):
+    """Adam.createJob / AMSGrad.createJob body with numpy scalar types (J/opt/grad/Adam.java:86-146, AMSGrad.java:100-160)."""
+    b1, b2, eps, lr = F(0.9), F(0.999), F(1e-7), F(0.05)
+    corr = float(lr) * math.sqrt(1 - math.pow(float(b2), iteration + 1)) / (1 - math.pow(float(b1), iteration + 1))
+    foc, ctx = st["focus"][bu], st["context"][bv]
+    s = F(0)
+    for d in range(D): s = F(s + F(foc[d] * ctx[d]))
+    ic = F(float(s) + (float(F(st["fbias"][bu] + st["cbias"][bv])) - math.log(float(X))))
+    wc = ic if float(X) > xmax else F(F(math.pow(float(X) / xmax, 0.75)) * ic)
+    cost = F(float(cost) + 0.5 * float(wc) * float(ic))
+    omb1, omb2 = F(F(1) - b1), F(F(1) - b2)
+
+    def mom(g, m_old, v_old):
+        m = F(F(b1 * m_old) + F(omb1 * g))
+        v = F(F(b2 * v_old) + F(omb2 * F(g * g)))
+        if ams: v = v if v_old <= v else v_old
+        return m, v
+
+    def step(par, m, v):
+        if ams: return F(float(par) - float(lr) / (math.sqrt(float(v)) + float(eps)) * float(m))
+        return F(float(par) - corr * float(m) / (math.sqrt(float(v)) + float(eps)))
+    for d in range(D):
+        gu, gv = F(wc * ctx[d]), F(wc * foc[d])
+        m1, v1 = mom(gu, st["gsq_focus"][bu][d], st["m2_focus"][bu][d])
+        m2, v2 = mom(gv, st["gsq_context"][bv][d], st["m2_context"][bv][d])
+        foc[d] = step(foc[d], m1, v1); ctx[d] = step(ctx[d], m2, v2)
+        st["gsq_focus"][bu][d], st["m2_focus"][bu][d] = m1, v1
+        st["gsq_context"][bv][d], st["m2_context"][bv][d] = m2, v2
+    m1, v1 = mom(wc, st["gsq_fbias"][bu], st["m2_fbias"][bu]); m2, v2 = mom(wc, st["gsq_cbias"][bv], st["m2_cbias"][bv])
+    st["fbias"][bu] = step(st["fbias"][bu], m1, v1); st["cbias"][bv] = step(st["cbias"][bv], m2, v2)
+    st["gsq_fbias"][bu], st["m2_fbias"][bu], st["gsq_cbias"][bv], st["m2_cbias"][bv] = m1, v1, m2, v2
+    return cost
+
+
+@pytest.mark.parametrize("opt,ams", [(O.OPT_ADAM, False), (O.OPT_AMSGRAD, True)])
+def test_adam_amsgrad_against_independent_python_model(opt, ams):
+    V, D = 10, 4
+    I, J, X, xmax = synth.synthetic_coo(V, 50, seed=6)
+    g = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=3, threads=1, opt=opt)
+    assert np.all(g.gsq_focus == 0) and np.all(g.m2_cbias == 0)          # moments start at zero (new float[])
+    st = g.state()
+    for it in range(2):                                                   # iteration enters Adam's bias correction
+        c = g.epoch()
+        cost = F(0)
+        for k in g.perm:
+            cost = py_adam_update(ams, it, O.COST_GLOVE, xmax, D, st, int(I[k]), int(J[k]), X[k], cost)
+        assert c == float(cost) / len(I)
+        for k, v in g.state().items():
+            assert np.array_equal(v, st[k]), (k, it)
