@@ -119,8 +119,7 @@ def main():
             ptr, cnt = opt.device_ptr(name)
             return torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=dev)
 
-        sync = parallel.ContextSync(params=[(wrap("context"), D), (wrap("cbias"), 1)],
-                                    accums=[wrap("gsq_context"), wrap("gsq_cbias")])
+        sync = parallel.ContextSync(sums=[wrap("context"), wrap("gsq_context"), wrap("gsq_cbias")], means=[wrap("cbias")])
 
     def step(it):
         c = opt.epoch(it)
@@ -186,7 +185,7 @@ def main():
                                    "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, %s Hogwild, per-epoch device shuffle"
                                    % (world, "s" if world > 1 else "", V, n_local, D, args.method, opt.getName()),
                        "vocab": V, "nnz_per_gpu": n_local, "dim": D, "cost": args.method, "opt": args.opt,
-                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce (mean over contributing ranks) every %d step(s)"
+                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce (rows and accumulators summed, biases averaged) every %d step(s)"
                                       % (world, args.sync_every) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "traffic": traffic,

@@ -73,6 +73,8 @@ struct BcaParams {
     unsigned long long *pool_used;     // bump allocator
     unsigned long long *queue;         // next bookmark
     int32_t *status;                   // 0 ok, 1 table overflow, 2 active-list overflow, 3 pool overflow
+    const int32_t *redo;               // second launch: the bookmarks (relative to row_begin) whose rows did not fit
+    int32_t n_jobs;                    // number of jobs in this launch (all rows, or the redo list)
 };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -248,13 +250,12 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
     // table starts empty
     for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY;
     wave_sync();
-    const int32_t n_rows = p.row_end - p.row_begin;
-
     for (;;) {
         unsigned long long ticket = 0;
         if (lane == 0) ticket = atomicAdd(p.queue, 1ull);
-        const int32_t r = rfl((int)ticket);
-        if (r >= n_rows || ticket >= (unsigned long long)n_rows) break;
+        const int32_t job = rfl((int)ticket);
+        if (job >= p.n_jobs || ticket >= (unsigned long long)p.n_jobs) break;
+        const int32_t r = p.redo ? p.redo[job] : job;
         const int32_t bookmark = p.row_begin + r;
         int32_t n_touched = 0, nf = 0, nr = 0;
         int32_t status = 0;
@@ -341,7 +342,14 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
                 off = (int64_t)o;
             }
             off = ((int64_t)(unsigned)rfl((int)(off >> 32)) << 32) | (unsigned)rfl((int)(off & 0xFFFFFFFFll));
-            if (off + n_out > p.out_cap) { status = 3; ok = false; }
+            bool fits = true;
+            if (off + n_out > p.out_cap) { fits = false; }      // the row size is known: it is re-run alone into an exact pool
+            if (!fits) {
+                if (lane == 0) { p.row_n[r] = n_out; p.row_off[r] = -1; p.row_max[r] = 1.0f; atomicMax(p.status, 3); }
+                for (int e = lane; e < n_touched && e < p.hc / 2; e += 64) w.hkey[w.touched[e]] = KEY_EMPTY;
+                wave_sync();
+                continue;
+            }
             if (ok) {
                 for (int e = lane; e < n_cand; e += 64) {
                     const unsigned long long me = w.okey[e];
@@ -427,15 +435,19 @@ __global__ void k_totals(BcaGraph g, double *tot_out, double *tot_in, double *to
 }
 
 // rows from the pool -> bookmark order
-__global__ void k_gather_rows(const int32_t *poolJ, const float *poolX, const int64_t *row_off, const int32_t *row_n,
+__global__ void k_gather_rows(const int32_t *poolJ, const float *poolX, const int32_t *pool2J, const float *pool2X, int64_t pool_cap,
+                              const int64_t *row_off, const int32_t *row_n,
                               const int64_t *dst_off, int32_t n_rows, int32_t row_begin,
                               int32_t *I, int32_t *J, float *X) {
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x / 64;
     for (int32_t r = blockIdx.x * wpb + (threadIdx.x >> 6); r < n_rows; r += gridDim.x * wpb) {
-        const int64_t so = row_off[r], d = dst_off[r];
+        int64_t so = row_off[r];
+        const int64_t d = dst_off[r];
         const int32_t n = row_n[r];
-        for (int k = lane; k < n; k += 64) { I[d + k] = row_begin + r; J[d + k] = poolJ[so + k]; X[d + k] = poolX[so + k]; }
+        const int32_t *sJ = poolJ; const float *sX = poolX;
+        if (so >= pool_cap) { so -= pool_cap; sJ = pool2J; sX = pool2X; }     // row lives in the second pool
+        for (int k = lane; k < n; k += 64) { I[d + k] = row_begin + r; J[d + k] = sJ[so + k]; X[d + k] = sX[so + k]; }
     }
 }
 
@@ -537,10 +549,16 @@ ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_b
     int64_t ac = (int64_t)std::min<double>((double)V, std::ceil(1.0 / cfg->epsilon) + 2.0) + 64;
     int64_t hc = 2048;
     while (hc < 4 * std::min<int64_t>(V, 256)) hc <<= 1;
-    int64_t pool_cap = std::max<int64_t>((int64_t)n_rows * 16, 1 << 16);
+    int64_t pool_cap = std::max<int64_t>((int64_t)n_rows * 128, 1 << 16);
+    if (const char *e = std::getenv("GE_BCA_POOL")) pool_cap = std::max<int64_t>(64, std::atoll(e));
     if (const char *e = std::getenv("GE_BCA_TABLE")) hc = std::max<int64_t>(64, std::atoll(e));
     int32_t *d_pJ = nullptr; float *d_pX = nullptr; char *d_work = nullptr;
     std::vector<int32_t> h_n((size_t)n_rows);
+    // Rows are written into a pool whose size is a guess; a row that does not fit still reports its size, and only
+    // those rows are run again into a second pool of exactly the missing size (no bookmark is computed twice in vain
+    // unless a WORK table overflows, in which case everything is repeated with larger tables).
+    int32_t *d_pJ2 = nullptr; float *d_pX2 = nullptr; int32_t *d_redo = nullptr;
+    std::vector<int64_t> h_off((size_t)n_rows);
     for (int attempt = 0;; ++attempt) {
         if (attempt > 12) return ge::fail(GE_ERR_OVERFLOW, "BCA work buffers kept overflowing (table %lld, active list %lld, pool %lld)", (long long)hc, (long long)ac, (long long)pool_cap);
         int hl = 0; while ((1ll << hl) < hc) ++hl;
@@ -561,7 +579,7 @@ ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_b
             return ge::fail(GE_ERR_OOM, "device allocation failed for BCA work buffers (table %lld slots x %lld waves, pool %lld)", (long long)hc, (long long)n_waves, (long long)pool_cap);
         }
         p.hc = (int32_t)hc; p.hc_log2 = hl; p.ac = (int32_t)ac; p.work = d_work; p.work_stride = stride;
-        p.outJ = d_pJ; p.outX = d_pX; p.out_cap = pool_cap;
+        p.outJ = d_pJ; p.outX = d_pX; p.out_cap = pool_cap; p.redo = nullptr; p.n_jobs = n_rows;
         hipError_t e = hipMemset(d_ctr, 0, 32);
         if (e == hipSuccess) { hipLaunchKernelGGL(k_bca, dim3((unsigned)n_waves), dim3(64), 0, 0, p); e = hipGetLastError(); }
         if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -569,11 +587,35 @@ ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_b
         if (e == hipSuccess) e = hipMemcpy(h_ctr, d_ctr, 32, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_HIP, "BCA kernel failed: %s", hipGetErrorString(e)); }
         const int32_t status = (int32_t)(h_ctr[2] & 0xFFFFFFFFull);
-        const int64_t used = (int64_t)h_ctr[0];
-        if (status == 0 && used <= pool_cap) break;
-        if (status == 1) hc *= 4;
-        else if (status == 2) ac = std::min<int64_t>(ac * 4, (int64_t)V + 64);
-        if (used > pool_cap || status == 3) pool_cap = std::max<int64_t>(used + used / 8 + 1024, pool_cap * 2);
+        if (status == 0) break;
+        if (status == 1) { hc *= 4; continue; }
+        if (status == 2) { ac = std::min<int64_t>(ac * 4, (int64_t)V + 64); continue; }
+        // status 3: some rows did not fit.  Re-run exactly those into a pool of exactly their size.
+        e = hipMemcpy(h_n.data(), d_row_n, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(h_off.data(), d_row_off, sizeof(int64_t) * (size_t)n_rows, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_HIP, "copy back failed: %s", hipGetErrorString(e)); }
+        std::vector<int32_t> redo; int64_t need = 0;
+        for (int32_t r = 0; r < n_rows; ++r) if (h_off[(size_t)r] < 0) { redo.push_back(r); need += h_n[(size_t)r]; }
+        const int64_t cap2 = need + 64;
+        bool good = hipMalloc((void **)&d_pJ2, sizeof(int32_t) * (size_t)cap2) == hipSuccess;
+        good = good && hipMalloc((void **)&d_pX2, sizeof(float) * (size_t)cap2) == hipSuccess;
+        good = good && hipMalloc((void **)&d_redo, sizeof(int32_t) * redo.size()) == hipSuccess;
+        if (d_pJ2) dev.keep(d_pJ2);
+        if (d_pX2) dev.keep(d_pX2);
+        if (d_redo) dev.keep(d_redo);
+        if (!good) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_OOM, "device allocation failed for the second BCA pool (%lld entries)", (long long)cap2); }
+        e = hipMemcpy(d_redo, redo.data(), sizeof(int32_t) * redo.size(), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(d_ctr, 0, 32);
+        // second-pool offsets are stored shifted by pool_cap so that one gather kernel can tell the pools apart
+        p.outJ = d_pJ2 - pool_cap; p.outX = d_pX2 - pool_cap; p.out_cap = pool_cap + cap2; p.redo = d_redo; p.n_jobs = (int32_t)redo.size();
+        unsigned long long used0 = (unsigned long long)pool_cap;
+        if (e == hipSuccess) e = hipMemcpy(d_ctr, &used0, 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_bca, dim3((unsigned)std::min<int64_t>(n_waves, (int64_t)redo.size())), dim3(64), 0, 0, p); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(h_ctr, d_ctr, 32, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_HIP, "BCA kernel (second pool) failed: %s", hipGetErrorString(e)); }
+        if ((int32_t)(h_ctr[2] & 0xFFFFFFFFull) != 0) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_OVERFLOW, "BCA second pool overflowed (internal sizing error)"); }
+        break;
     }
     dev.keep(d_work); dev.keep(d_pJ); dev.keep(d_pX);
 
@@ -608,7 +650,7 @@ ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_b
         e = hipMemcpy(d_dst, dst.data(), sizeof(int64_t) * (size_t)n_rows, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)std::min<int64_t>((n_rows + 3) / 4, 65535)), dim3(256), 0, 0,
-                               d_pJ, d_pX, d_row_off, d_row_n, d_dst, n_rows, rb, d_I, d_J, d_X);
+                               d_pJ, d_pX, d_pJ2, d_pX2, pool_cap, d_row_off, d_row_n, d_dst, n_rows, rb, d_I, d_J, d_X);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpy(c->I.data(), d_I, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);

@@ -113,6 +113,14 @@ def test_table_growth_path(gpu, monkeypatch):
     _check(g)
 
 
+def test_row_pool_overflow_path(gpu, monkeypatch):
+    """A row pool that is far too small: the rows that did not fit are re-run alone into a second, exact pool."""
+    monkeypatch.setenv("GE_BCA_POOL", "1000")
+    g = synth.dblp_like_graph(300, 500, 4)
+    _check(g)
+    _check(g, normalize="unity")
+
+
 def test_bad_arguments(gpu):
     g = _graph(3, [(0, 1)])
     with pytest.raises(geglove.GeError) as e:

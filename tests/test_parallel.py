@@ -30,8 +30,7 @@ def _rank_main(rank, world, port, V, N, D, epochs, q):
     base = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)       # same init on every rank
     st = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in base.state().items()}
     view = {k: t.numpy() for k, t in st.items()}                                 # oracle updates torch memory in place
-    sync = parallel.ContextSync(params=[(st["context"].view(-1), D), (st["cbias"], 1)],
-                                accums=[st["gsq_context"].view(-1), st["gsq_cbias"]])
+    sync = parallel.ContextSync(sums=[st["context"].view(-1), st["gsq_context"].view(-1), st["gsq_cbias"]], means=[st["cbias"]])
     rng = np.random.default_rng(100 + rank)
     costs = []
     for _ in range(epochs):
@@ -84,11 +83,11 @@ def test_two_ranks_stay_replicated_and_track_the_single_process_run():
     np.testing.assert_allclose(costs, ref, rtol=0.10)              # statistical parity of the sharded run
 
 
-def test_context_sync_merge_rule_single_process_math():
-    """world_size 1 group inside this process: the rule itself on hand-made deltas (2 fake ranks folded by hand)."""
-    old = np.array([[1., 1.], [2., 2.], [3., 3.]], np.float32)
-    d0 = np.array([[.5, 0.], [0., 0.], [1., 1.]], np.float32)      # rank 0 touched rows 0, 2
-    d1 = np.array([[0., 0.], [0., 0.], [3., -1.]], np.float32)     # rank 1 touched row 2
-    cnt = ((np.abs(d0).max(1) > 0).astype(np.float32) + (np.abs(d1).max(1) > 0))
-    exp = old + (d0 + d1) / np.maximum(cnt, 1)[:, None]
-    np.testing.assert_array_equal(exp, [[1.5, 1.], [2., 2.], [5., 3.]])
+def test_context_sync_merge_rule_math():
+    """The rule itself on hand-made deltas of two fake ranks: sums add, means average over the ranks that moved."""
+    old = np.array([1., 2., 3.], np.float32)
+    d0 = np.array([.5, 0., 1.], np.float32)       # rank 0 changed elements 0 and 2
+    d1 = np.array([0., 0., 3.], np.float32)       # rank 1 changed element 2
+    np.testing.assert_array_equal(old + d0 + d1, [1.5, 2., 7.])                                   # `sums`
+    cnt = (d0 != 0).astype(np.float32) + (d1 != 0)
+    np.testing.assert_array_equal(old + (d0 + d1) / np.maximum(cnt, 1), [1.5, 2., 5.])            # `means`
