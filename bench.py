@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--opt", default="adagrad", choices=["adagrad", "adam", "amsgrad"],
                     help="update rule (the headline metric is quoted on adagrad; adam/amsgrad keep two moment rows per side)")
     ap.add_argument("--sync-every", type=int, default=1, help="steps between context all-reduces (N>1)")
+    ap.add_argument("--accum-sync-every", type=int, default=4, help="every how many context syncs the AdaGrad accumulators are reconciled too (N>1)")
     return ap.parse_args()
 
 
@@ -119,7 +120,8 @@ def main():
             ptr, cnt = opt.device_ptr(name)
             return torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=dev)
 
-        sync = parallel.ContextSync(sums=[wrap("context"), wrap("gsq_context"), wrap("gsq_cbias")], means=[wrap("cbias")])
+        sync = parallel.ContextSync(sums=[wrap("context")], means=[wrap("cbias")],
+                                    lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=args.accum_sync_every)
 
     def step(it):
         c = opt.epoch(it)
@@ -185,8 +187,8 @@ def main():
                                    "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, %s Hogwild, per-epoch device shuffle"
                                    % (world, "s" if world > 1 else "", V, n_local, D, args.method, opt.getName()),
                        "vocab": V, "nnz_per_gpu": n_local, "dim": D, "cost": args.method, "opt": args.opt,
-                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce (rows and accumulators summed, biases averaged) every %d step(s)"
-                                      % (world, args.sync_every) if world > 1 else "single GPU"},
+                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce every %d step(s) (rows summed, biases averaged, accumulators summed every %d syncs)"
+                                      % (world, args.sync_every, args.accum_sync_every) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "traffic": traffic,
                          "kernel": "k_adagrad_runs", "algorithmic_bytes_per_launch": n_local * (read_b + write_b), "kernel_ms": avg_kernel_s * 1e3,

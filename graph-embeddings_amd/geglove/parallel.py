@@ -56,22 +56,34 @@ class ContextSync:
     Works on CPU tensors with gloo (tests) and on device memory with nccl = RCCL over xGMI (bench.py).
     """
 
-    def __init__(self, sums, means, group=None):
+    def __init__(self, sums, means, lazy_sums=(), lazy_every=4, group=None):
+        """lazy_sums: `sums` tables that are reconciled only every `lazy_every`-th call -- the AdaGrad accumulators:
+        between syncs each rank keeps adding its own squared gradients (its steps are then at most sqrt(world)
+        larger than with the global sum); the oracle simulation shows no difference in the cost trajectory
+        (within 1 %) between syncing them every step, every 4th step or never, and it halves the bytes."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self.world = dist.get_world_size(group)
         self.sums = list(sums)
+        self.lazy = list(lazy_sums)
+        self.lazy_every = max(1, int(lazy_every))
         self.means = list(means)
         self.old_s = [t.clone() for t in self.sums]
+        self.old_l = [t.clone() for t in self.lazy]
         self.old_m = [t.clone() for t in self.means]
+        self.calls = 0
 
     def sync(self):
         if self.world == 1:
             return
         torch, dist = self.torch, self.dist
+        self.calls += 1
+        pairs = list(zip(self.sums, self.old_s))
+        if self.calls % self.lazy_every == 0:
+            pairs += list(zip(self.lazy, self.old_l))
         work, counts = [], []
-        for t, o in zip(self.sums, self.old_s):
+        for t, o in pairs:
             t.sub_(o)                                                   # t now holds this rank's delta
             work.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for t, o in zip(self.means, self.old_m):
@@ -82,7 +94,7 @@ class ContextSync:
             work.append(dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in work:
             w.wait()
-        for t, o in zip(self.sums, self.old_s):
+        for t, o in pairs:
             t.add_(o)
             o.copy_(t)
         for t, o, cnt in zip(self.means, self.old_m, counts):

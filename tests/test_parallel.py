@@ -30,7 +30,8 @@ def _rank_main(rank, world, port, V, N, D, epochs, q):
     base = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)       # same init on every rank
     st = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in base.state().items()}
     view = {k: t.numpy() for k, t in st.items()}                                 # oracle updates torch memory in place
-    sync = parallel.ContextSync(sums=[st["context"].view(-1), st["gsq_context"].view(-1), st["gsq_cbias"]], means=[st["cbias"]])
+    sync = parallel.ContextSync(sums=[st["context"].view(-1)], means=[st["cbias"]],
+                                lazy_sums=[st["gsq_context"].view(-1), st["gsq_cbias"]], lazy_every=2)
     rng = np.random.default_rng(100 + rank)
     costs = []
     for _ in range(epochs):
@@ -39,6 +40,7 @@ def _rank_main(rank, world, port, V, N, D, epochs, q):
         sync.sync()
         t = torch.tensor([c], dtype=torch.float64); dist.all_reduce(t)
         costs.append(float(t.item()) / len(I))
+    # epochs is a multiple of lazy_every, so the accumulators were reconciled by the last sync as well
     digest = torch.tensor([float(st[k].double().sum()) for k in CTX], dtype=torch.float64)
     gathered = [torch.zeros_like(digest) for _ in range(world)]
     dist.all_gather(gathered, digest)

@@ -37,7 +37,7 @@ def _rank_main(rank, world, port, q):
 
     ctx = wrap("context")
     assert ctx.data_ptr() == opt.device_ptr("context")[0]                       # zero copy
-    sync = parallel.ContextSync(sums=[ctx, wrap("gsq_context"), wrap("gsq_cbias")], means=[wrap("cbias")])
+    sync = parallel.ContextSync(sums=[ctx], means=[wrap("cbias")], lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=2)
     costs = []
     for it in range(EPOCHS):
         c = opt.epoch(it)
