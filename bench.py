@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--hot", default="auto", choices=["auto", "none", "all"])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="storage of the embedding rows; bf16 = BASELINE config C5 (fp32 accumulators, stochastic rounding)")
     ap.add_argument("--opt", default="adagrad", choices=["adagrad", "adam", "amsgrad"],
                     help="update rule (the headline metric is quoted on adagrad; adam/amsgrad keep two moment rows per side)")
     ap.add_argument("--sync-every", type=int, default=1, help="steps between context all-reduces (N>1)")
@@ -108,7 +110,7 @@ def main():
         "bca": {"alpha": 0.1, "epsilon": 1e-3, "directed": True},
         "opt": {"method": args.opt, "tolerance": 0, "maxiter": args.steps},
         "output": {"uri": []},
-        "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot,
+        "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot, "dtype": args.dtype,
                    "row_range": rows if world > 1 else (0, 0)}})
     opt = geglove.createOptimizer(cfg, geglove.CooMatrix(V, I, J, X, xmax))
 
@@ -167,12 +169,14 @@ def main():
         if os.path.exists(tpath):
             try:
                 for t in json.load(open(tpath)):
-                    if (t["vocab"], t["nnz_per_gpu"], t["dim"], t["cost"]) == (V, n_local, D, args.method) and world == 1 and args.opt == "adagrad":
+                    if (t["vocab"], t["nnz_per_gpu"], t["dim"], t["cost"]) == (V, n_local, D, args.method) and world == 1 and args.opt == "adagrad" and args.dtype == "f32":
                         traffic = t["traffic_bytes_per_launch"]
             except Exception:
                 traffic = None
         # algorithmic bytes per pair-update (8f for the moment optimisers: one more row per side)
         read_b, write_b = (16 * D + 28, 16 * D + 16) if args.opt == "adagrad" else (24 * D + 36, 24 * D + 24)
+        if args.dtype == "bf16":
+            read_b, write_b = 12 * D + 28, 12 * D + 16
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
         ach = n_local * (read_b + write_b) / avg_kernel_s / 1e9          # GB/s, rank 0's kernel
         out = {
@@ -182,7 +186,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.dtype == "f32" else "bf16 rows + f32 accumulators (f32 arithmetic)", "data": "synthetic",
             "config": {"workload": "synthetic hub-heavy co-occurrence matrix (BASELINE C4 recipe scaled to %d GPU%s): "
                                    "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, %s Hogwild, per-epoch device shuffle"
                                    % (world, "s" if world > 1 else "", V, n_local, D, args.method, opt.getName()),

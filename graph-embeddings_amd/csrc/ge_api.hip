@@ -34,6 +34,8 @@ const char *ge_last_error(void) { return ge::last_error_buf(); }
 
 const char *ge_version(void) { return "geglove 0.1.0 (gfx950)"; }
 
+int32_t ge_glove_cfg_size(void) { return (int32_t)sizeof(ge_glove_cfg); }
+
 int32_t ge_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);

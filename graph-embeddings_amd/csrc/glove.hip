@@ -33,6 +33,8 @@ struct GloveParams {
     float *m2f, *m2c, *m2fb, *m2cb;          // Adam/AMSGrad.M2*
     double correction;                       // Adam: lr*sqrt(1-beta2^(t+1))/(1-beta1^(t+1))  (Adam.java:84), per epoch
     int32_t opt;                             // GE_OPT_*
+    float *hub32;                            // bf16 embeddings: fp32 master rows of the hub columns [n_hub x D]
+    const int32_t *hub_index;                // bf16 embeddings: column -> row of hub32, -1 for ordinary columns
     const int32_t *I, *J;
     const float *X;
     const int32_t *perm;
@@ -143,6 +145,31 @@ __global__ void k_extract(const float *focus, const float *context, OUT *out, in
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) out[i] = (OUT)((focus[i] + context[i]) / 2.0f);
+}
+
+// bf16 embeddings (BASELINE config C5): storage conversions.  Round-to-nearest-even on the way in (init, set_state).
+__global__ void k_f32_to_bf16(const float *src, uint16_t *dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t u = __builtin_bit_cast(uint32_t, src[i]);
+        dst[i] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+    }
+}
+__global__ void k_bf16_to_f32(const uint16_t *src, float *dst, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = __builtin_bit_cast(float, (uint32_t)src[i] << 16);
+}
+// hub rows live in the fp32 master table: dir 0 = full[col] -> hub32[idx], dir 1 = hub32[idx] -> full[col]
+__global__ void k_hub_rows(float *full, float *hub32, const int32_t *hub_index, int32_t V, int32_t D, int dir) {
+    const int32_t v = blockIdx.x;
+    const int32_t h = hub_index[v];
+    if (h < 0) return;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        if (dir == 0) hub32[(int64_t)h * D + d] = full[(int64_t)v * D + d];
+        else full[(int64_t)v * D + d] = hub32[(int64_t)h * D + d];
+    }
 }
 
 // ---- exact (deterministic) kernel -------------------------------------------------------
@@ -311,10 +338,44 @@ constexpr int RUN_CHUNK = 128;            // nonzeros per worker chunk (2 per la
 constexpr int KEY_PAD = 0x7FFFFFFF;       // sorts last; marks the unused tail of the last chunk
 
 // OPT: GE_OPT_ADAGRAD keeps one auxiliary row per side (gradSq), Adam / AMSGrad two (M1, M2).
-template <int VW, int NCH, int OPT>
+// EMB16: the embedding rows (focus, context) are stored as bf16, everything else stays fp32 (BASELINE config C5).
+//   Rows are widened to fp32 when loaded; a resident row stays fp32 in registers for its whole run and is
+//   narrowed once, with STOCHASTIC rounding (an update of 1e-5 on a value of 0.1 is far below half a bf16 ulp and
+//   would always round away).  Hub context rows keep an fp32 master copy (hub32) that their runs read and
+//   publish into with the same atomics as in the fp32 build; they never touch the bf16 table during training.
+template <int VW, int NCH, int OPT, bool EMB16>
 __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_workers) {
     using VT = typename Vec<VW>::T;
+    static_assert(!EMB16 || VW == 4, "bf16 embeddings need dim % 4 == 0");
     constexpr bool MOM = OPT != GE_OPT_ADAGRAD;
+    uint32_t sr_state = 0x9E3779B9u * (uint32_t)(threadIdx.x + 1) + (uint32_t)blockIdx.x * 0x85EBCA6Bu + p.bij_key[0];
+    // embedding-row access: fp32 build = plain 16-byte vectors; bf16 build = 8 bytes widened / narrowed here
+    auto emb_rsrc = [&](float *base, int64_t id) {
+        if constexpr (EMB16) return make_rsrc(reinterpret_cast<uint16_t *>(base) + id * p.D, (uint32_t)p.D * 2u);
+        else return make_rsrc(base + id * p.D, (uint32_t)p.D * 4u);
+    };
+    auto emb_load = [&](__amdgpu_buffer_rsrc_t rs, int q) -> VT {
+        if constexpr (EMB16) {
+            const float2 raw = buf_load<2, AUX_SC1>(rs, ((threadIdx.x & 63) + q * 64) * 8);
+            const uint32_t lo = __builtin_bit_cast(uint32_t, raw.x), hi = __builtin_bit_cast(uint32_t, raw.y);
+            VT r;
+            r.x = __builtin_bit_cast(float, lo << 16); r.y = __builtin_bit_cast(float, lo & 0xFFFF0000u);
+            r.z = __builtin_bit_cast(float, hi << 16); r.w = __builtin_bit_cast(float, hi & 0xFFFF0000u);
+            return r;
+        } else return buf_load<VW, AUX_SC1>(rs, ((threadIdx.x & 63) + q * 64) * VW * 4);
+    };
+    auto emb_store = [&](VT v, __amdgpu_buffer_rsrc_t rs, int q) {
+        if constexpr (EMB16) {
+            auto narrow = [&](float f) -> uint32_t {      // stochastic rounding: add 16 random low bits, truncate
+                sr_state = sr_state * 1664525u + 1013904223u;
+                return (__builtin_bit_cast(uint32_t, f) + (sr_state >> 16)) >> 16;
+            };
+            float2 raw;
+            raw.x = __builtin_bit_cast(float, narrow(v.x) | (narrow(v.y) << 16));
+            raw.y = __builtin_bit_cast(float, narrow(v.z) | (narrow(v.w) << 16));
+            buf_store<2>(raw, rs, ((threadIdx.x & 63) + q * 64) * 8);
+        } else buf_store<VW>(v, rs, ((threadIdx.x & 63) + q * 64) * VW * 4);
+    };
     constexpr float BETA1 = 0.9f, BETA2 = 0.999f, EPS = 1e-7f, OMB1 = 1 - BETA1, OMB2 = 1 - BETA2;   // Adam.java:45-53
     const float corr = OPT == GE_OPT_ADAM ? (float)p.correction : p.lr;      // Adam.java:84 | AMSGrad.java:133 uses lr itself
     // one element of an Adam / AMSGrad update in fp32: new moments and the parameter step
@@ -415,6 +476,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
         // resident row changes there) its resident rows are already in flight.  They are requested BEFORE
         // this nonzero's stores, so waiting for them never waits for a store to retire.
         int32_t cur_id = 0; bool cur_hot = false;
+        bool cur_a32 = !EMB16, n_a32 = !EMB16;       // EMB16: resident parameter row lives in hub32 (fp32) for hub chunks
         VT a[NCH], ga[NCH], ha[NCH], a0[NCH], ga0[NCH];     // ha = second moment (MOM); ga0 = gradSq as read (AdaGrad)
         float ab = 0.0f, gab = 0.0f, hab = 0.0f;
         __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A_rows, 0), rs_ga = rs_a, rs_ha = rs_a;
@@ -428,7 +490,8 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             if (!cur_hot || MOM) {
 #pragma unroll
                 for (int q = 0; q < NCH; ++q) {
-                    buf_store<VW>(a[q], rs_a, (lane + q * 64) * VW * 4);
+                    if (EMB16 && !cur_a32) emb_store(a[q], rs_a, q);
+                    else buf_store<VW>(a[q], rs_a, (lane + q * 64) * VW * 4);
                     buf_store<VW>(ga[q], rs_ga, (lane + q * 64) * VW * 4);
                     if constexpr (MOM) buf_store<VW>(ha[q], rs_ha, (lane + q * 64) * VW * 4);
                 }
@@ -493,12 +556,12 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             n_l = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
         };
         auto request_streamed = [&]() {
-            const __amdgpu_buffer_rsrc_t rb = make_rsrc(B_rows + (int64_t)n_oth * D, row_bytes);
+            const __amdgpu_buffer_rsrc_t rb = emb_rsrc(B_rows, n_oth);
             const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)n_oth * D, row_bytes);
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)n_oth * D, MOM ? row_bytes : 0u);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
-                nb[q]  = buf_load<VW, AUX_SC1>(rb, (lane + q * 64) * VW * 4);
+                nb[q]  = emb_load(rb, q);
                 ngb[q] = buf_load<VW, AUX_SC1>(rg, (lane + q * 64) * VW * 4);
                 if constexpr (MOM) nhb[q] = buf_load<VW, AUX_SC1>(rh, (lane + q * 64) * VW * 4);
             }
@@ -508,12 +571,17 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
         };
         auto request_resident = [&]() {
             const int32_t id = n_key < 0 ? ~n_key : n_key;
-            rsN_a = make_rsrc(A_rows + (int64_t)id * D, row_bytes);
+            if constexpr (EMB16) {
+                n_a32 = res_is_ctx && p.hot_enabled != 0;                  // hub chunk: fp32 master row
+                if (n_a32) rsN_a = make_rsrc(p.hub32 + (int64_t)p.hub_index[id] * D, row_bytes);
+                else rsN_a = emb_rsrc(A_rows, id);
+            } else rsN_a = make_rsrc(A_rows + (int64_t)id * D, row_bytes);
             rsN_ga = make_rsrc(A_gs + (int64_t)id * D, row_bytes);
             rsN_ha = make_rsrc(A_m2 + (int64_t)id * D, MOM ? row_bytes : 0u);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
-                aN[q]  = buf_load<VW, AUX_SC1>(rsN_a, (lane + q * 64) * VW * 4);
+                if (EMB16 && !n_a32) aN[q] = emb_load(rsN_a, q);
+                else aN[q] = buf_load<VW, AUX_SC1>(rsN_a, (lane + q * 64) * VW * 4);
                 gaN[q] = buf_load<VW, AUX_SC1>(rsN_ga, (lane + q * 64) * VW * 4);
                 if constexpr (MOM) haN[q] = buf_load<VW, AUX_SC1>(rsN_ha, (lane + q * 64) * VW * 4);
             }
@@ -543,6 +611,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
                 cur_id = skey < 0 ? ~skey : skey;
                 cur_hot = res_is_ctx && (p.blocked ? p.hot_enabled != 0 : skey < 0);
                 rs_a = rsN_a; rs_ga = rsN_ga; rs_ha = rsN_ha;
+                cur_a32 = n_a32;
                 run_len = 0;
             }
             const bool last = pos + 1 >= n_valid;
@@ -567,7 +636,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             const float wc = w * ic;
             cost_acc += (0.5 * (double)wc) * (double)ic;
             const float wlr = wc * lr;
-            const __amdgpu_buffer_rsrc_t rb = make_rsrc(B_rows + (int64_t)b_id * D, row_bytes);
+            const __amdgpu_buffer_rsrc_t rb = emb_rsrc(B_rows, b_id);
             const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)b_id * D, row_bytes);
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)b_id * D, MOM ? row_bytes : 0u);
 #pragma unroll
@@ -591,7 +660,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
                             comp<VW>(a[q], t) = av - moment_step(grad_a, comp<VW>(ga[q], t), comp<VW>(ha[q], t));
                         }
                     }
-                    buf_store<VW>(ob, rb, (lane + q * 64) * VW * 4);
+                    emb_store(ob, rb, q);
                     buf_store<VW>(ogb, rg, (lane + q * 64) * VW * 4);
                     if constexpr (MOM) buf_store<VW>(ohb, rh, (lane + q * 64) * VW * 4);
                 }
@@ -628,20 +697,30 @@ using hogwild_fn = void (*)(GloveParams, int32_t);
 template <int VW, int OPT>
 hogwild_fn pick_nch(int nch) {
     switch (nch) {
-        case 1: return k_adagrad_runs<VW, 1, OPT>;
-        case 2: return k_adagrad_runs<VW, 2, OPT>;
-        case 3: return k_adagrad_runs<VW, 3, OPT>;
-        case 4: return k_adagrad_runs<VW, 4, OPT>;
+        case 1: return k_adagrad_runs<VW, 1, OPT, false>;
+        case 2: return k_adagrad_runs<VW, 2, OPT, false>;
+        case 3: return k_adagrad_runs<VW, 3, OPT, false>;
+        case 4: return k_adagrad_runs<VW, 4, OPT, false>;
+        default: return nullptr;
+    }
+}
+hogwild_fn pick_bf16(int nch) {       // bf16 embeddings: AdaGrad, dim % 4 == 0
+    switch (nch) {
+        case 1: return k_adagrad_runs<4, 1, GE_OPT_ADAGRAD, true>;
+        case 2: return k_adagrad_runs<4, 2, GE_OPT_ADAGRAD, true>;
+        case 3: return k_adagrad_runs<4, 3, GE_OPT_ADAGRAD, true>;
+        case 4: return k_adagrad_runs<4, 4, GE_OPT_ADAGRAD, true>;
         default: return nullptr;
     }
 }
 template <int OPT>
 hogwild_fn pick_vw(int vw, int nch) { return vw == 4 ? pick_nch<4, OPT>(nch) : vw == 2 ? pick_nch<2, OPT>(nch) : pick_nch<1, OPT>(nch); }
 // One wavefront spans a row: 64 lanes x VW floats x NCH chunks >= D.
-hogwild_fn pick_hogwild(int D, int opt, int *vw_out, int *nch_out) {
+hogwild_fn pick_hogwild(int D, int opt, bool emb16, int *vw_out, int *nch_out) {
     const int vw = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
     const int nch = (D + 64 * vw - 1) / (64 * vw);
-    hogwild_fn fn = opt == GE_OPT_ADAGRAD ? pick_vw<GE_OPT_ADAGRAD>(vw, nch)
+    hogwild_fn fn = emb16 ? pick_bf16(nch)
+                  : opt == GE_OPT_ADAGRAD ? pick_vw<GE_OPT_ADAGRAD>(vw, nch)
                   : opt == GE_OPT_ADAM ? pick_vw<GE_OPT_ADAM>(vw, nch) : pick_vw<GE_OPT_AMSGRAD>(vw, nch);
     *vw_out = vw; *nch_out = nch;
     return fn;
@@ -679,6 +758,11 @@ struct ge_glove {
     int64_t n_chunks = 0, n_hchunks = 0;
     int32_t *dbA = nullptr, *dbB = nullptr, *dchunk_flush = nullptr;
     int flush_every = RUN_CHUNK;
+    bool emb16 = false;               // focus/context stored as bf16 (tab[] pointers then address uint16 data)
+    float *hub32 = nullptr;           // bf16 build: fp32 master rows of the hub columns
+    int32_t *dhub_index = nullptr;
+    std::vector<int32_t> host_hub_index;
+    int32_t n_hub = 0;
     std::vector<int32_t> host_key;    // sort key per (re-ordered) position: what the kernel stages as `key`
     std::vector<int32_t> host_border; // blocked layout: original nonzero per position (-1 = padding)
     int32_t hot_cols = 0;
@@ -702,13 +786,16 @@ void fill_params(const ge_glove *h, GloveParams &p, int32_t iteration) {
     p.m2f = h->tab[GE_STATE_M2_FOCUS];    p.m2c = h->tab[GE_STATE_M2_CONTEXT];
     p.m2fb = h->tab[GE_STATE_M2_FBIAS];   p.m2cb = h->tab[GE_STATE_M2_CBIAS];
     p.opt = h->cfg.opt;
+    p.hub32 = h->hub32; p.hub_index = h->dhub_index;
     {   // Adam.java:84, evaluated in fp64 from the fp32 constants exactly as the Java expression does
         const float lrf = h->cfg.learning_rate, b1 = 0.9f, b2 = 0.999f;
         p.correction = (double)lrf * std::sqrt(1 - std::pow((double)b2, (double)(iteration + 1))) / (1 - std::pow((double)b1, (double)(iteration + 1)));
     }
     // focus-side tables hold rows [row_begin,row_end): rebase so that kernels index by global row id
     const int64_t off = h->cfg.row_begin;
-    p.focus -= off * h->cfg.dim;  p.gsf -= off * h->cfg.dim;
+    if (h->emb16) p.focus = reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(p.focus) - off * h->cfg.dim);
+    else p.focus -= off * h->cfg.dim;
+    p.gsf -= off * h->cfg.dim;
     p.fbias -= off;               p.gsfb -= off;
     if (p.m2f) { p.m2f -= off * h->cfg.dim; p.m2fb -= off; }
     p.I = h->dI; p.J = h->dJ; p.X = h->dX; p.perm = h->dperm; p.L = h->dL; p.W = h->dW;
@@ -769,6 +856,10 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     if (cfg->mode != GE_MODE_HOGWILD && cfg->mode != GE_MODE_DETERMINISTIC) return ge::fail(GE_ERR_ARG, "invalid mode %d", cfg->mode);
     if (cfg->shuffle < GE_SHUFFLE_JAVA || cfg->shuffle > GE_SHUFFLE_NONE) return ge::fail(GE_ERR_ARG, "invalid shuffle %d", cfg->shuffle);
     if (cfg->workers < 0) return ge::fail(GE_ERR_ARG, "workers must be >= 0");
+    if (cfg->emb_dtype != GE_DTYPE_F32 && cfg->emb_dtype != GE_DTYPE_BF16) return ge::fail(GE_ERR_ARG, "invalid emb_dtype %d", cfg->emb_dtype);
+    const bool emb16 = cfg->emb_dtype == GE_DTYPE_BF16;
+    if (emb16 && (cfg->mode != GE_MODE_HOGWILD || cfg->shuffle != GE_SHUFFLE_DEVICE || cfg->opt != GE_OPT_ADAGRAD || cfg->dim % 4 != 0))
+        return ge::fail(GE_ERR_ARG, "bf16 embeddings need mode=hogwild, shuffle=device, opt=adagrad and dim %% 4 == 0 (the reference path is fp32)");
     if (cfg->hot_columns < GE_HOT_AUTO || cfg->hot_columns > GE_HOT_ALL) return ge::fail(GE_ERR_ARG, "invalid hot_columns %d", cfg->hot_columns);
     int32_t rb = cfg->row_begin, re = cfg->row_end;
     if (rb == 0 && re == 0) re = cfg->vocab_size;
@@ -783,6 +874,7 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     ge_glove *h = new (std::nothrow) ge_glove();
     if (!h) return ge::fail(GE_ERR_OOM, "host allocation failed");
     h->cfg = *cfg;
+    h->emb16 = emb16;
     h->cfg.row_begin = rb; h->cfg.row_end = re;
     h->rows = re - rb;
     h->stream = (hipStream_t)cfg->stream;
@@ -814,7 +906,7 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     if (cfg->mode == GE_MODE_HOGWILD) {
         if (const char *e = std::getenv("GE_GLOVE_BLOCKS_PER_CU")) h->hw_blocks_per_cu = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("GE_GLOVE_FLUSH_EVERY")) h->flush_every = std::max(1, std::atoi(e));
-        h->hw_fn = pick_hogwild(D, cfg->opt, &h->hw_vw, &h->hw_nch);
+        h->hw_fn = pick_hogwild(D, cfg->opt, emb16, &h->hw_vw, &h->hw_nch);
         if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 1024 for dim%%4==0, 256 for odd dim)", D); }
         // One wavefront = one sequential worker.  Never more workers than N/2048: a small matrix must
         // not degenerate into one giant stale batch (the JVM has at most #cores updates in flight).
@@ -844,6 +936,10 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
             for (int32_t v = 0; v < V; ++v)
                 if (cnt[(size_t)v] >= thr && cnt[(size_t)v] > 0) { hotcol[(size_t)v] = 1; ++h->hot_cols; h->hot_nnz += cnt[(size_t)v]; }
             h->hot_threshold = thr;
+        }
+        if (emb16) {
+            h->host_hub_index.assign((size_t)V, -1);
+            for (int32_t v = 0; v < V; ++v) if (hotcol[(size_t)v]) h->host_hub_index[(size_t)v] = h->n_hub++;
         }
         // Concurrent runs on one hub column add their deltas; each delta is stale by the length of the run.
         // Summing K concurrent runs of m updates behaves like one step K*m times too long, and diverges
@@ -968,6 +1064,23 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     }
     GE_TRY(hipGetLastError());
     GE_TRY(hipStreamSynchronize(h->stream));
+    if (emb16) {
+        // fp32 master rows of the hub columns, then narrow both embedding tables to bf16 (round to nearest even)
+        GE_TRY(hipMalloc((void **)&h->dhub_index, sizeof(int32_t) * (size_t)V));
+        GE_TRY(hipMemcpy(h->dhub_index, h->host_hub_index.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice));
+        GE_TRY(hipMalloc((void **)&h->hub32, sizeof(float) * (size_t)std::max<int64_t>((int64_t)h->n_hub * D, 1)));
+        hipLaunchKernelGGL(k_hub_rows, dim3((unsigned)V), dim3(64), 0, h->stream, h->tab[GE_STATE_CONTEXT], h->hub32, h->dhub_index, V, D, 0);
+        for (int t : {GE_STATE_FOCUS, GE_STATE_CONTEXT}) {
+            uint16_t *n16 = nullptr;
+            const int64_t n = h->tab_count[t];
+            GE_TRY(hipMalloc((void **)&n16, sizeof(uint16_t) * (size_t)std::max<int64_t>(n, 1)));
+            hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, h->stream, h->tab[t], n16, n);
+            GE_TRY(hipStreamSynchronize(h->stream));
+            (void)hipFree(h->tab[t]);
+            h->tab[t] = reinterpret_cast<float *>(n16);
+        }
+        GE_TRY(hipGetLastError());
+    }
     h->rng.s = ge::JavaRandom::jump(s0, (uint64_t)V * (uint64_t)(2 + 2 * D));
 
 #undef GE_TRY
@@ -1029,6 +1142,21 @@ ge_status ge_glove_epoch(ge_glove *h, int32_t iteration, double *cost_sum) {
     return GE_OK;
 }
 
+// bf16 build: an fp32 device copy of FOCUS or CONTEXT as the caller sees it (hub rows from their fp32 masters)
+static ge_status materialize_f32(ge_glove *h, int which, float **out) {
+    const int64_t n = h->tab_count[which];
+    float *d = nullptr;
+    GE_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)std::max<int64_t>(n, 1)));
+    hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, h->stream,
+                       reinterpret_cast<const uint16_t *>(h->tab[which]), d, n);
+    if (which == GE_STATE_CONTEXT && h->n_hub > 0)
+        hipLaunchKernelGGL(k_hub_rows, dim3((unsigned)h->cfg.vocab_size), dim3(64), 0, h->stream, d, h->hub32, h->dhub_index, h->cfg.vocab_size, h->cfg.dim, 1);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { (void)hipFree(d); return ge::fail(GE_ERR_HIP, "bf16 -> fp32 conversion failed: %s", hipGetErrorString(e)); }
+    *out = d;
+    return GE_OK;
+}
+
 static ge_status extract_impl(ge_glove *h, void *out, bool f64) {
     ge_status st = check_handle(h);
     if (st != GE_OK) return st;
@@ -1041,10 +1169,18 @@ static ge_status extract_impl(ge_glove *h, void *out, bool f64) {
     void *d = nullptr;
     GE_HIP(hipMalloc(&d, bytes));
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
-    if (f64) hipLaunchKernelGGL(k_extract<double>, dim3(blocks), dim3(256), 0, h->stream, h->tab[GE_STATE_FOCUS], h->tab[GE_STATE_CONTEXT], (double *)d, n);
-    else     hipLaunchKernelGGL(k_extract<float>,  dim3(blocks), dim3(256), 0, h->stream, h->tab[GE_STATE_FOCUS], h->tab[GE_STATE_CONTEXT], (float *)d, n);
+    float *foc = h->tab[GE_STATE_FOCUS], *ctx = h->tab[GE_STATE_CONTEXT];
+    if (h->emb16) {
+        foc = ctx = nullptr;
+        ge_status s1 = materialize_f32(h, GE_STATE_FOCUS, &foc);
+        ge_status s2 = s1 == GE_OK ? materialize_f32(h, GE_STATE_CONTEXT, &ctx) : s1;
+        if (s2 != GE_OK) { if (foc) (void)hipFree(foc); (void)hipFree(d); return s2; }
+    }
+    if (f64) hipLaunchKernelGGL(k_extract<double>, dim3(blocks), dim3(256), 0, h->stream, foc, ctx, (double *)d, n);
+    else     hipLaunchKernelGGL(k_extract<float>,  dim3(blocks), dim3(256), 0, h->stream, foc, ctx, (float *)d, n);
     hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (h->emb16) { (void)hipFree(foc); (void)hipFree(ctx); }
     (void)hipFree(d);
     if (e != hipSuccess) return ge::fail(GE_ERR_HIP, "extract copy failed: %s", hipGetErrorString(e));
     return GE_OK;
@@ -1057,6 +1193,16 @@ ge_status ge_glove_get_state(ge_glove *h, int32_t which, float *out, int64_t cou
     if (st != GE_OK) return st;
     if (which < 0 || which >= GE_STATE_COUNT || !out) return ge::fail(GE_ERR_ARG, "invalid state id %d or null buffer", which);
     if (count != h->tab_count[which]) return ge::fail(GE_ERR_ARG, "state %d holds %lld floats, caller passed %lld", which, (long long)h->tab_count[which], (long long)count);
+    if (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT)) {
+        float *d = nullptr;
+        st = materialize_f32(h, which, &d);
+        if (st != GE_OK) return st;
+        hipError_t e = hipMemcpyAsync(out, d, sizeof(float) * (size_t)count, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(d);
+        if (e != hipSuccess) return ge::fail(GE_ERR_HIP, "state copy failed: %s", hipGetErrorString(e));
+        return GE_OK;
+    }
     GE_HIP(hipMemcpyAsync(out, h->tab[which], sizeof(float) * (size_t)count, hipMemcpyDeviceToHost, h->stream));
     GE_HIP(hipStreamSynchronize(h->stream));
     return GE_OK;
@@ -1067,6 +1213,21 @@ ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_
     if (st != GE_OK) return st;
     if (which < 0 || which >= GE_STATE_COUNT || !in) return ge::fail(GE_ERR_ARG, "invalid state id %d or null buffer", which);
     if (count != h->tab_count[which]) return ge::fail(GE_ERR_ARG, "state %d holds %lld floats, caller passed %lld", which, (long long)h->tab_count[which], (long long)count);
+    if (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT)) {
+        float *d = nullptr;
+        GE_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)std::max<int64_t>(count, 1)));
+        hipError_t e = hipMemcpyAsync(d, in, sizeof(float) * (size_t)count, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            if (which == GE_STATE_CONTEXT && h->n_hub > 0)
+                hipLaunchKernelGGL(k_hub_rows, dim3((unsigned)h->cfg.vocab_size), dim3(64), 0, h->stream, d, h->hub32, h->dhub_index, h->cfg.vocab_size, h->cfg.dim, 0);
+            hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 8192)), dim3(256), 0, h->stream,
+                               d, reinterpret_cast<uint16_t *>(h->tab[which]), count);
+            e = hipStreamSynchronize(h->stream);
+        }
+        (void)hipFree(d);
+        if (e != hipSuccess) return ge::fail(GE_ERR_HIP, "state copy failed: %s", hipGetErrorString(e));
+        return GE_OK;
+    }
     GE_HIP(hipMemcpyAsync(h->tab[which], in, sizeof(float) * (size_t)count, hipMemcpyHostToDevice, h->stream));
     GE_HIP(hipStreamSynchronize(h->stream));
     return GE_OK;
@@ -1075,6 +1236,8 @@ ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_
 ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *count) {
     if (!h) return ge::fail(GE_ERR_ARG, "null ge_glove handle");
     if (which < 0 || which >= GE_STATE_COUNT || !dptr) return ge::fail(GE_ERR_ARG, "invalid state id %d or null out", which);
+    if (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT))
+        return ge::fail(GE_ERR_STATE, "table %d is stored as bf16 (+ fp32 hub rows); use ge_glove_get_state/set_state", which);
     *dptr = h->tab[which];
     if (count) *count = h->tab_count[which];
     return GE_OK;
@@ -1150,6 +1313,8 @@ void ge_glove_destroy(ge_glove *h) {
     if (h->dperm) (void)hipFree(h->dperm);
     if (h->dbA) (void)hipFree(h->dbA);
     if (h->dbB) (void)hipFree(h->dbB);
+    if (h->hub32) (void)hipFree(h->hub32);
+    if (h->dhub_index) (void)hipFree(h->dhub_index);
     if (h->dchunk_flush) (void)hipFree(h->dchunk_flush);
     if (h->dL) (void)hipFree(h->dL);
     if (h->dW) (void)hipFree(h->dW);

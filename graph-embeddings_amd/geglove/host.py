@@ -230,6 +230,7 @@ class Adagrad:
         cfg.row_begin, cfg.row_end = rb, re
         cfg.hot_columns = _HOT[str(dev.get("hot", "auto")).lower()]
         cfg.workers = int(dev.get("workers", 0))
+        cfg.emb_dtype = {"f32": capi.GE_DTYPE_F32, "bf16": capi.GE_DTYPE_BF16}[str(dev.get("dtype", "f32")).lower()]
         self._rows = (re - rb) if (rb, re) != (0, 0) else self.vocabSize
         self._cfg = cfg
         self._h = C.c_void_p()

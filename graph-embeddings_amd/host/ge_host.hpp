@@ -582,6 +582,8 @@ public:
             int opt = GE_OPT_ADAGRAD, const char *name = "Adagrad")
         : coCount_(m.coOccurrenceCount()), vocab_(m.vocabSize()), dim_(config.dim), maxIter_(config.opt.maxiter),
           tolerance_(config.opt.tolerance), progress_(progress), name_(name) {
+        if (ge_glove_cfg_size() != (int32_t)sizeof(ge_glove_cfg))
+            throw std::runtime_error("libgeglove.so and this host were built from different revisions of include/geglove.h; rebuild both");
         ge_glove_cfg cfg;
         ge_glove_cfg_default(&cfg);
         cfg.opt = opt;

@@ -76,6 +76,12 @@ enum { GE_SHUFFLE_JAVA = 0, GE_SHUFFLE_DEVICE = 1, GE_SHUFFLE_NONE = 2 };
  * NONE: plain stores everywhere (the literal Java race).  ALL: every column (tests). */
 enum { GE_HOT_AUTO = 0, GE_HOT_NONE = 1, GE_HOT_ALL = 2 };
 
+/* Storage type of the embedding rows (focus, context).  BF16 is BASELINE config C5: bf16 rows, fp32 AdaGrad
+ * accumulators and biases, fp32 arithmetic; rows are narrowed with stochastic rounding, hub context rows keep an
+ * fp32 master copy.  HOGWILD + GE_SHUFFLE_DEVICE + ADAGRAD + dim % 4 == 0 only (the reference is fp32 throughout,
+ * so there is no bit-exact mode for it); every API still speaks fp32 (get/set/extract convert). */
+enum { GE_DTYPE_F32 = 0, GE_DTYPE_BF16 = 1 };
+
 /* Parameter tables a caller can read or write (tests, checkpointing, multi-GPU sync). */
 enum {
     GE_STATE_FOCUS = 0,        /* float[V*D]  Optimizer.focus         (J/opt/Optimizer.java:27) */
@@ -120,6 +126,7 @@ typedef struct {
     int32_t workers;        /* HOGWILD: number of sequential workers (wavefronts); 0 = fill the device.
                                Workers pull chunks of 128 consecutive nonzeros of the epoch order from a queue
                                and walk each chunk in stable column order; workers = 1 is fully sequential. */
+    int32_t emb_dtype;      /* GE_DTYPE_*: storage of the focus/context rows                           */
 } ge_glove_cfg;
 
 /* What the library decided for a handle (reporting / DESIGN.md numbers). */
@@ -223,6 +230,9 @@ void ge_coo_destroy(ge_coo *c);
 /* ------------------------------------------------------------------------------------------ */
 const char *ge_last_error(void);     /* message of the calling thread's last failed call */
 const char *ge_version(void);
+/* sizeof(ge_glove_cfg) as the LIBRARY was compiled: a host built against another header revision must refuse to
+ * run instead of letting ge_glove_cfg_default write past its struct. */
+int32_t ge_glove_cfg_size(void);
 /* Number of visible HIP devices that are gfx950; <0 on HIP error. Does not compute. */
 int32_t ge_device_count(void);
 

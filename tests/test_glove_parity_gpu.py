@@ -318,3 +318,87 @@ def test_adam_amsgrad_hogwild_trajectory(gpu, opt):
     # Asserted: finite, falling, and within a factor 2 of the sequential oracle from the third epoch on.
     assert np.all(np.isfinite(d)) and d[-1] < d[0]
     assert np.all(d[2:] < 2.0 * r[2:]) and np.all(d[2:] > 0.5 * r[2:])
+
+
+# ------------------------------------------------------------------ bf16 embeddings (BASELINE config C5)
+def _bf16_rne(a):
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("hot", ["none", "all"])
+@pytest.mark.parametrize("D", [52, 200, 300])
+def test_bf16_embeddings_conflict_free_batch(gpu, D, hot):
+    """bf16 rows + fp32 accumulators: one update per row, compared with the oracle applied to the SAME (bf16-valued)
+    start state.  Accumulators and biases are fp32 and must agree to fp32 round-off; embedding rows are narrowed
+    with stochastic rounding, so they agree to one bf16 ulp and the rounding error has zero mean.  With hot=all the
+    context rows live in their fp32 master table and agree to fp32 round-off as well."""
+    V = 5000
+    I, J, X = synth.conflict_free_batch(V, 4096, seed=D)
+    cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, hot=hot, dtype="bf16")
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, 0.2), cfg, cfg.costFunction())
+    st = opt.state()
+    ora = O.Glove(V, D, I, J, X, 0.2, O.COST_GLOVE, seed=42, threads=1)
+    # init = Java draw order, rounded to nearest-even bf16 (hub context rows keep the fp32 value: hot=all => every row)
+    assert np.array_equal(st["focus"].reshape(V, D), _bf16_rne(ora.focus))
+    exp_ctx = _bf16_rne(ora.context)
+    if hot == "all":
+        exp_ctx[np.unique(J)] = ora.context[np.unique(J)]          # every column that occurs is a hub
+    assert np.array_equal(st["context"].reshape(V, D), exp_ctx)
+    ref = {k: (v.reshape(V, -1) if v.size == V * D else v).astype(np.float32, copy=True) for k, v in st.items()}
+    O.adagrad_job(D, I, J, X, 0.2, O.COST_GLOVE, ref)
+    opt.epoch(0)
+    got = opt.state()
+    for k in ("fbias", "cbias", "gsq_focus", "gsq_context", "gsq_fbias", "gsq_cbias"):
+        np.testing.assert_allclose(got[k], ref[k].reshape(-1), rtol=3e-6, atol=1e-9, err_msg=k)
+    tables = ["focus"] if hot == "all" else ["focus", "context"]
+    if hot == "all":
+        np.testing.assert_allclose(got["context"], ref["context"].reshape(-1), rtol=3e-6, atol=2e-7 * float(np.max(np.abs(ref["context"]))))
+    for k in tables:
+        g, r = got[k], ref[k].reshape(-1)
+        touched = np.zeros(V, bool); touched[I if k == "focus" else J] = True
+        m = np.repeat(touched, D)
+        ulp = np.maximum(np.abs(r[m]), 1e-30) * 2.0 ** -7          # one bf16 ulp is between 2^-8 and 2^-7 of the value
+        err = (g[m] - r[m]) / ulp
+        # fp32 round-off of the update itself (reduction order, rsqrt) is allowed on top, as in the fp32 test
+        slack = 2e-7 * float(np.max(np.abs(r))) / ulp
+        assert np.all(np.abs(err) <= 1.0 + slack), (k, float(np.max(np.abs(err) - slack)))
+        assert abs(np.mean(err)) < 0.01, (k, float(np.mean(err)))  # stochastic rounding is unbiased
+        assert np.array_equal(g[~m], st[k][~m])                     # untouched rows are untouched
+
+
+def test_bf16_embeddings_state_roundtrip_and_extract(gpu):
+    V, D = 300, 64
+    I, J, X, xmax = synth.synthetic_coo(V, 6000, seed=4)
+    cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=1, dtype="bf16")
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+    rng = np.random.default_rng(0)
+    new = rng.standard_normal(V * D).astype(np.float32)
+    opt.set_state("focus", new)
+    np.testing.assert_array_equal(opt.get_state("focus"), _bf16_rne(new))
+    opt.set_state("context", new)
+    got = opt.get_state("context").reshape(V, D)
+    hubs = np.unique(J[np.isin(J, np.nonzero(np.bincount(J, minlength=V) >= opt.info()["hot_threshold"])[0])])
+    exact = np.zeros(V, bool); exact[hubs] = True
+    np.testing.assert_array_equal(got[exact], new.reshape(V, D)[exact])            # hub rows keep fp32
+    np.testing.assert_array_equal(got[~exact], _bf16_rne(new).reshape(V, D)[~exact])
+    np.testing.assert_allclose(opt.extractResultF32(), (opt.get_state("focus") + opt.get_state("context")) / 2, rtol=1e-6)
+    with pytest.raises(geglove.GeError):
+        opt.device_ptr("context")
+    with pytest.raises(geglove.GeError):           # the reference path is fp32: no deterministic bf16 mode
+        geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), make_config(D, "glove", mode="deterministic", shuffle="java", dtype="bf16"), GloveCostless())
+
+
+@pytest.mark.parametrize("method", ["glove", "pglove"])
+def test_bf16_embeddings_trajectory(gpu, method):
+    """Training with bf16 rows follows the fp32 oracle: from the third epoch on within 5 % per epoch."""
+    V, N, D = 20000, 600000, 52
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
+    cfg = make_config(D, method, mode="hogwild", shuffle="device", seed=42, dtype="bf16")
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+    ora = O.Glove(V, D, I, J, X, xmax, cost_kind(method), seed=42, threads=1)
+    n = len(I)
+    dev = np.array([opt.epoch(it) / n for it in range(8)])
+    ref = np.array([ora.epoch() for _ in range(8)])
+    assert np.all(np.isfinite(dev)) and dev[-1] < dev[0]
+    np.testing.assert_allclose(dev[2:], ref[2:], rtol=0.05)
