@@ -229,7 +229,8 @@ struct Configuration {
     struct Output { bool present = false; std::string name; bool has_uri = false, has_blank = false, has_predicate = false, has_literal = false;
                     std::vector<std::string> uri, blank, predicate, literal; } output;
     // new, optional block `device:` (never changes the meaning of a reference key)
-    struct { std::string mode = "hogwild", shuffle = "device", hot = "auto"; long long seed = 0; bool has_seed = false; int id = 0; int workers = 0; } device;
+    struct { std::string mode = "hogwild", shuffle = "device", hot = "auto", dtype = "f32", save_coo, load_coo;
+             long long seed = 0; bool has_seed = false; int id = 0; int workers = 0; } device;
     std::vector<std::string> ignored_keys;     // legacy keys of the shipped YAMLs that the bean does not know
 
     int getThreads() const {       // Configuration.java:71-73
@@ -313,6 +314,9 @@ struct Configuration {
                     else if (q.first == "seed") { c.device.seed = std::strtoll(q.second.scalar.c_str(), nullptr, 10); c.device.has_seed = true; }
                     else if (q.first == "id") c.device.id = (int)num(&q.second);
                     else if (q.first == "workers") c.device.workers = (int)num(&q.second);
+                    else if (q.first == "dtype") c.device.dtype = q.second.scalar;
+                    else if (q.first == "save_coo") c.device.save_coo = q.second.scalar;      // COO checkpoint
+                    else if (q.first == "load_coo") c.device.load_coo = q.second.scalar;
                 }
             } else c.ignored_keys.push_back(k);
         }
@@ -560,6 +564,61 @@ private:
     int64_t nnz_ = 0; const int32_t *I_ = nullptr, *J_ = nullptr; const float *X_ = nullptr; double max_ = 0;
 };
 
+// COO checkpoint (the reference has no on-disk form of the matrix, the format is ours):
+//   "GECOO1\0\0" | int32 V | int64 nnz | double max | int32 I[nnz] | int32 J[nnz] | float X[nnz] |
+//   V x { int8 type, int32 key_len, key bytes }
+// It decouples the builder from the trainer: `device.save_coo` writes it after BCA, `device.load_coo` starts from it.
+class StoredCooMatrix : public CoOccurrenceMatrix {
+public:
+    static void save(const std::string &path, const CoOccurrenceMatrix &m) {
+        std::ofstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error("cannot write " + path);
+        const int32_t V = m.vocabSize(); const int64_t n = m.coOccurrenceCount(); const double mx = m.max();
+        f.write("GECOO1\0\0", 8);
+        f.write((const char *)&V, 4); f.write((const char *)&n, 8); f.write((const char *)&mx, 8);
+        f.write((const char *)m.dataI(), 4 * n); f.write((const char *)m.dataJ(), 4 * n); f.write((const char *)m.dataX(), 4 * n);
+        for (int32_t v = 0; v < V; ++v) {
+            const int8_t t = m.getType(v); const std::string k = m.getKey(v); const int32_t len = (int32_t)k.size();
+            f.write((const char *)&t, 1); f.write((const char *)&len, 4); f.write(k.data(), len);
+        }
+        if (!f) throw std::runtime_error("short write on " + path);
+    }
+    explicit StoredCooMatrix(const std::string &path) {
+        std::ifstream f(path, std::ios::binary);
+        char magic[8];
+        if (!f || !f.read(magic, 8) || std::memcmp(magic, "GECOO1\0\0", 8) != 0) throw std::runtime_error(path + " is not a geglove COO checkpoint");
+        int64_t n = 0;
+        f.read((char *)&V_, 4); f.read((char *)&n, 8); f.read((char *)&max_, 8);
+        if (!f || V_ <= 0 || n < 0) throw std::runtime_error("corrupt COO checkpoint " + path);
+        I_.resize((size_t)n); J_.resize((size_t)n); X_.resize((size_t)n);
+        f.read((char *)I_.data(), 4 * n); f.read((char *)J_.data(), 4 * n); f.read((char *)X_.data(), 4 * n);
+        keys_.resize((size_t)V_); types_.resize((size_t)V_);
+        for (int32_t v = 0; v < V_; ++v) {
+            int32_t len = 0;
+            f.read((char *)&types_[(size_t)v], 1); f.read((char *)&len, 4);
+            if (!f || len < 0 || len > (1 << 24)) throw std::runtime_error("corrupt COO checkpoint " + path);
+            keys_[(size_t)v].resize((size_t)len); f.read(&keys_[(size_t)v][0], len);
+        }
+        if (!f) throw std::runtime_error("truncated COO checkpoint " + path);
+    }
+    int vocabSize() const override { return V_; }
+    double max() const override { return max_; }
+    std::string getKey(int index) const override { return keys_[(size_t)index]; }
+    int8_t getType(int index) const override { return types_[(size_t)index]; }
+    int cIdx_I(int i) const override { return I_[(size_t)i]; }
+    int cIdx_J(int j) const override { return J_[(size_t)j]; }
+    float cIdx_C(int i) const override { return X_[(size_t)i]; }
+    int coOccurrenceCount() const override { return (int)I_.size(); }
+    void shuffle() override {}
+    const int32_t *dataI() const override { return I_.data(); }
+    const int32_t *dataJ() const override { return J_.data(); }
+    const float *dataX() const override { return X_.data(); }
+private:
+    int32_t V_ = 0; double max_ = 0;
+    std::vector<int32_t> I_, J_; std::vector<float> X_;
+    std::vector<std::string> keys_; std::vector<int8_t> types_;
+};
+
 // ------------------------------------------------------------------------------------------------
 // Optimizer
 // ------------------------------------------------------------------------------------------------
@@ -597,6 +656,7 @@ public:
         cfg.shuffle = config.device.shuffle == "java" ? GE_SHUFFLE_JAVA : config.device.shuffle == "none" ? GE_SHUFFLE_NONE : GE_SHUFFLE_DEVICE;
         cfg.hot_columns = config.device.hot == "none" ? GE_HOT_NONE : config.device.hot == "all" ? GE_HOT_ALL : GE_HOT_AUTO;
         cfg.workers = config.device.workers;
+        cfg.emb_dtype = config.device.dtype == "bf16" ? GE_DTYPE_BF16 : GE_DTYPE_F32;
         cfg.device = config.device.id;
         ge_glove *h = nullptr;
         check(ge_glove_create(&cfg, m.dataI(), m.dataJ(), m.dataX(), &h));

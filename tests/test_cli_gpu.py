@@ -76,3 +76,26 @@ def test_cli_error_paths(gpu, tmp_path):
     assert r.returncode == 1 and "Invalid configuration: No dimension specified" in r.stderr
     r = subprocess.run([EXE, "-c"], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 1 and "No configuration file specified, exiting..." in r.stderr
+
+
+def test_cli_coo_checkpoint_and_other_optimisers(gpu, tmp_path):
+    """device.save_coo / device.load_coo give the same vectors as the direct run; opt.method
+    adam is accepted (Main.createOptimizer, J/Main.java:121-130)."""
+    cwd = tmp_path
+    os.makedirs(cwd / "tests" / "golden")
+    (cwd / "tests" / "golden" / "tiny.nt").write_bytes(open(os.path.join(REPO, "tests", "golden", "tiny.nt"), "rb").read())
+    base = open(os.path.join(REPO, "tests", "golden", "tiny.config.yml")).read()
+    (cwd / "a.yml").write_text(base.replace("  seed: 42", "  seed: 42\n  save_coo: tiny.gecoo") + "\n")
+    (cwd / "b.yml").write_text(base.replace("  seed: 42", "  seed: 42\n  load_coo: tiny.gecoo").replace("graph: tests/golden/tiny.nt", "graph: missing.nt") + "\n")
+    name = "tiny_pglove_partial_directed_0.1_0.001_adagrad_pca_8"
+    r = subprocess.run([EXE, "-c", "a.yml"], cwd=cwd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    first = (cwd / "out" / (name + ".vectors.tsv")).read_text()
+    os.remove(cwd / "out" / (name + ".vectors.tsv"))
+    r = subprocess.run([EXE, "-c", "b.yml"], cwd=cwd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "loaded COO checkpoint tiny.gecoo" in r.stdout, r.stderr + r.stdout
+    second = (cwd / "out" / "missing_pglove_partial_directed_0.1_0.001_adagrad_pca_8.vectors.tsv").read_text()
+    assert first.splitlines()[2:] == second.splitlines()[2:]            # same numbers (the header names the graph file)
+    (cwd / "c.yml").write_text(base.replace("method: adagrad", "method: adam"))
+    r = subprocess.run([EXE, "-c", "c.yml"], cwd=cwd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and os.path.exists(cwd / "out" / "tiny_pglove_partial_directed_0.1_0.001_adam_pca_8.vectors.tsv"), r.stderr
