@@ -92,8 +92,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # GE_BENCH_BACKEND=gloo + GE_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank flow with every rank on GPU 0
+        # (RCCL refuses two ranks per device); never used by the driver.
+        if os.environ.get("GE_BENCH_ONE_DEVICE") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("GE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if capi.lib().ge_device_count() <= 0:
         raise SystemExit("bench.py needs a gfx950 GPU: " + capi.lib().ge_last_error().decode())
 
