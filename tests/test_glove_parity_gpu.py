@@ -402,3 +402,45 @@ def test_bf16_embeddings_trajectory(gpu, method):
     ref = np.array([ora.epoch() for _ in range(8)])
     assert np.all(np.isfinite(dev)) and dev[-1] < dev[0]
     np.testing.assert_allclose(dev[2:], ref[2:], rtol=0.05)
+
+
+# ------------------------------------------------------------------ quality of the trained vectors
+def _cos_matrix(E):
+    E = E / np.maximum(np.linalg.norm(E, axis=1, keepdims=True), 1e-30)
+    return E @ E.T
+
+
+def test_hogwild_trained_vectors_are_as_good_as_sequential(gpu):
+    """What the user gets are the vectors.  Two SEQUENTIAL oracle runs that differ only in the order of the
+    updates already disagree element-wise, so vectors are compared through their pairwise-cosine matrix (invariant to
+    what SGD leaves undetermined): the device's Hogwild run must correlate with the Java-order oracle run at least as
+    well (minus 0.02) as another sequential oracle run does, and reach the same final cost within 3 %."""
+    g = synth.dblp_like_graph(250, 380, 6)
+    coo = O.bca_build(g["V"], g["out"], g["inn"], 0.1, 1e-3, True, O.NORM_NONE)
+    V, D, EP = g["V"], 24, 25
+    I, J, X, xmax = coo["I"], coo["J"], coo["X"], coo["max"]
+    n = len(I)
+    ora = O.Glove(V, D, I, J, X, xmax, O.COST_PGLOVE, seed=42, threads=1)
+    for _ in range(EP):
+        c_ref = ora.epoch()
+    E_ref = ora.extract()
+    # a second sequential run: same init, other (uniformly random) orders
+    ora2 = O.Glove(V, D, I, J, X, xmax, O.COST_PGLOVE, seed=42, threads=1)
+    st = {k: np.ascontiguousarray(v) for k, v in ora2.state().items()}
+    rng = np.random.default_rng(5)
+    for _ in range(EP):
+        p = rng.permutation(n)
+        c_alt = O.adagrad_job(D, I[p], J[p], X[p], xmax, O.COST_PGLOVE, st) / n
+    E_alt = (st["focus"] + st["context"]) / 2
+    cfg = make_config(D, "pglove", mode="hogwild", shuffle="device", seed=42)
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+    for it in range(EP):
+        c_dev = opt.epoch(it) / n
+    E_dev = opt.extractResult().reshape(V, D)
+    iu = np.triu_indices(V, 1)
+    rho_alt = np.corrcoef(_cos_matrix(E_ref)[iu], _cos_matrix(E_alt)[iu])[0, 1]
+    rho_dev = np.corrcoef(_cos_matrix(E_ref)[iu], _cos_matrix(E_dev)[iu])[0, 1]
+    print("pairwise-cosine correlation with the Java-order oracle: other sequential order %.4f, device Hogwild %.4f; final cost %.6f / %.6f / %.6f" % (rho_alt, rho_dev, c_ref, c_alt, c_dev))
+    assert rho_alt > 0.9                                    # the comparison is meaningful
+    assert rho_dev >= rho_alt - 0.02, (rho_dev, rho_alt)
+    assert abs(c_dev / c_ref - 1) <= 0.03 and abs(c_alt / c_ref - 1) <= 0.03, (c_dev, c_alt, c_ref)
