@@ -896,8 +896,11 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
         if (counts[t] > 0) GE_TRY(hipMalloc((void **)&h->tab[t], sizeof(float) * (size_t)counts[t]));
     }
     const size_t nn = (size_t)std::max<int64_t>(N, 1);
-    GE_TRY(hipMalloc((void **)&h->dI, sizeof(int32_t) * nn));
-    GE_TRY(hipMalloc((void **)&h->dJ, sizeof(int32_t) * nn));
+    const bool will_block = cfg->mode == GE_MODE_HOGWILD && cfg->shuffle == GE_SHUFFLE_DEVICE;   // blocked layout: bA/bB replace I/J
+    if (!will_block) {
+        GE_TRY(hipMalloc((void **)&h->dI, sizeof(int32_t) * nn));
+        GE_TRY(hipMalloc((void **)&h->dJ, sizeof(int32_t) * nn));
+    }
     GE_TRY(hipMalloc((void **)&h->dX, sizeof(float) * nn));
     GE_TRY(hipMalloc((void **)&h->dcost, 2 * sizeof(double)));
     GE_TRY(hipMalloc((void **)&h->djob, sizeof(float) * (size_t)cfg->threads));
