@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--opt", default="adagrad", choices=["adagrad", "adam", "amsgrad"],
                     help="update rule (the headline metric is quoted on adagrad; adam/amsgrad keep two moment rows per side)")
     ap.add_argument("--sync-every", type=int, default=1, help="steps between context all-reduces (N>1)")
+    ap.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="dtype of the deltas on the wire (N>1)")
     ap.add_argument("--accum-sync-every", type=int, default=4, help="every how many context syncs the AdaGrad accumulators are reconciled too (N>1)")
     return ap.parse_args()
 
@@ -131,7 +132,8 @@ def main():
             return torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=dev)
 
         sync = parallel.ContextSync(sums=[wrap("context")], means=[wrap("cbias")],
-                                    lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=args.accum_sync_every)
+                                    lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=args.accum_sync_every,
+                                    wire=args.wire)
 
     def step(it):
         c = opt.epoch(it)
@@ -199,8 +201,8 @@ def main():
                                    "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, %s Hogwild, per-epoch device shuffle"
                                    % (world, "s" if world > 1 else "", V, n_local, D, args.method, opt.getName()),
                        "vocab": V, "nnz_per_gpu": n_local, "dim": D, "cost": args.method, "opt": args.opt,
-                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce every %d step(s) (rows summed, biases averaged, accumulators summed every %d syncs)"
-                                      % (world, args.sync_every, args.accum_sync_every) if world > 1 else "single GPU"},
+                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce every %d step(s) (rows summed, biases averaged, accumulators summed every %d syncs, %s on the wire)"
+                                      % (world, args.sync_every, args.accum_sync_every, args.wire) if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "traffic": traffic,
                          "kernel": "k_adagrad_runs", "algorithmic_bytes_per_launch": n_local * (read_b + write_b), "kernel_ms": avg_kernel_s * 1e3,

@@ -21,7 +21,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _rank_main(rank, world, port, V, N, D, epochs, q):
+def _rank_main(rank, world, port, V, N, D, epochs, q, wire="bf16"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
@@ -31,7 +31,7 @@ def _rank_main(rank, world, port, V, N, D, epochs, q):
     st = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in base.state().items()}
     view = {k: t.numpy() for k, t in st.items()}                                 # oracle updates torch memory in place
     sync = parallel.ContextSync(sums=[st["context"].view(-1)], means=[st["cbias"]],
-                                lazy_sums=[st["gsq_context"].view(-1), st["gsq_cbias"]], lazy_every=2)
+                                lazy_sums=[st["gsq_context"].view(-1), st["gsq_cbias"]], lazy_every=2, wire=wire)
     rng = np.random.default_rng(100 + rank)
     costs = []
     for _ in range(epochs):
@@ -49,11 +49,11 @@ def _rank_main(rank, world, port, V, N, D, epochs, q):
     dist.destroy_process_group()
 
 
-def _run(world, V=1500, N=40000, D=8, epochs=4):
+def _run(world, V=1500, N=40000, D=8, epochs=4, wire="bf16"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, world, port, V, N, D, epochs, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank_main, args=(r, world, port, V, N, D, epochs, q, wire)) for r in range(world)]
     for p in procs: p.start()
     out = q.get(timeout=300)
     for p in procs: p.join(timeout=60)
@@ -75,11 +75,12 @@ def test_shard_rows_and_nonzeros_partition_the_matrix():
         assert np.all((p[0] >= b) & (p[0] < e))
 
 
-def test_two_ranks_stay_replicated_and_track_the_single_process_run():
-    costs, digests, _ = _run(2)
+@pytest.mark.parametrize("wire,V,D", [("f32", 1500, 8), ("bf16", 140000, 8)])     # the large table crosses the bf16-wire threshold
+def test_two_ranks_stay_replicated_and_track_the_single_process_run(wire, V, D):
+    costs, digests, _ = _run(2, V=V, N=40000 if V == 1500 else 400000, D=D, wire=wire)
     assert digests[0] == digests[1]                                # context side identical on both ranks after sync
-    I, J, X, xmax = synth.synthetic_coo(1500, 40000, seed=13)
-    ora = O.Glove(1500, 8, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
+    I, J, X, xmax = synth.synthetic_coo(V, 40000 if V == 1500 else 400000, seed=13)
+    ora = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
     ref = [ora.epoch() for _ in range(4)]
     assert np.all(np.isfinite(costs)) and costs[-1] < costs[0]
     np.testing.assert_allclose(costs, ref, rtol=0.10)              # statistical parity of the sharded run
