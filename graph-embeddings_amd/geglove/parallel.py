@@ -77,6 +77,7 @@ class ContextSync:
         self.old_l = [t.clone() for t in self.lazy]
         self.old_m = [t.clone() for t in self.means]
         self.calls = 0
+        self._wbuf = {}
 
     def sync(self):
         if self.world == 1:
@@ -88,8 +89,14 @@ class ContextSync:
             pairs += list(zip(self.lazy, self.old_l))
         work, counts, wired = [], [], []
         for t, o in pairs:
-            t.sub_(o)                                                   # t now holds this rank's delta
-            w = t.to(torch.bfloat16) if (self.wire == "bf16" and t.numel() >= (1 << 20)) else t
+            if self.wire == "bf16" and t.numel() >= (1 << 20):
+                w = self._wbuf.get(id(t))
+                if w is None:
+                    w = self._wbuf[id(t)] = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+                torch.sub(t, o, out=w)                                  # delta, narrowed in the same pass
+            else:
+                t.sub_(o)                                               # t now holds this rank's delta
+                w = t
             wired.append(w)
             work.append(dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for t, o in zip(self.means, self.old_m):
@@ -102,8 +109,9 @@ class ContextSync:
             w.wait()
         for (t, o), w in zip(pairs, wired):
             if w is not t:
-                t.copy_(w)                                              # widen the summed delta back to fp32
-            t.add_(o)
+                torch.add(o, w, out=t)                                  # old + summed delta, widened in the same pass
+            else:
+                t.add_(o)
             o.copy_(t)
         for t, o, cnt in zip(self.means, self.old_m, counts):
             t.div_(cnt.clamp_(min=1.0))
