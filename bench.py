@@ -41,6 +41,11 @@ def parse():
                     help="update rule (the headline metric is quoted on adagrad; adam/amsgrad keep two moment rows per side)")
     ap.add_argument("--sync-every", type=int, default=1, help="steps between context all-reduces (N>1)")
     ap.add_argument("--wire", default="bf16", choices=["bf16", "f32"], help="dtype of the deltas on the wire (N>1)")
+    ap.add_argument("--exchange", default="overlap", choices=["overlap", "sync"],
+                    help="N>1: 'overlap' runs the all-reduce of step k's context deltas under step k+1 (they land one step late); "
+                         "'sync' exchanges after every step before the next one starts")
+    ap.add_argument("--reserve-waves", type=int, default=256,
+                    help="N>1 with --exchange overlap: wavefront slots the epoch kernel leaves free for the all-reduce kernels")
     ap.add_argument("--accum-sync-every", type=int, default=4, help="every how many context syncs the AdaGrad accumulators are reconciled too (N>1)")
     return ap.parse_args()
 
@@ -120,6 +125,7 @@ def main():
         "opt": {"method": args.opt, "tolerance": 0, "maxiter": args.steps},
         "output": {"uri": []},
         "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot, "dtype": args.dtype,
+                   "workers": -args.reserve_waves if (world > 1 and args.exchange == "overlap") else 0,
                    "row_range": rows if world > 1 else (0, 0)}})
     opt = geglove.createOptimizer(cfg, geglove.CooMatrix(V, I, J, X, xmax))
 
@@ -138,7 +144,10 @@ def main():
     def step(it):
         c = opt.epoch(it)
         if sync is not None and (it + 1) % args.sync_every == 0:
-            sync.sync()
+            if args.exchange == "overlap":
+                sync.turn()                         # lands the deltas sent one exchange ago and sends this step's: the all-reduce runs under the next epoch
+            else:
+                sync.sync()
         return c
 
     def fence():
@@ -201,8 +210,10 @@ def main():
                                    "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, %s Hogwild, per-epoch device shuffle"
                                    % (world, "s" if world > 1 else "", V, n_local, D, args.method, opt.getName()),
                        "vocab": V, "nnz_per_gpu": n_local, "dim": D, "cost": args.method, "opt": args.opt,
-                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce every %d step(s) (rows summed, biases averaged, accumulators summed every %d syncs, %s on the wire)"
-                                      % (world, args.sync_every, args.accum_sync_every, args.wire) if world > 1 else "single GPU"},
+                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce every %d step(s) (rows summed, biases averaged, accumulators summed every %d syncs, %s on the wire, %s)"
+                                      % (world, args.sync_every, args.accum_sync_every, args.wire,
+                                         "overlapped with the next epoch, %d wavefront slots reserved" % args.reserve_waves if args.exchange == "overlap" else "synchronous")
+                                      if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "traffic": traffic,
                          "kernel": "k_adagrad_runs", "algorithmic_bytes_per_launch": n_local * (read_b + write_b), "kernel_ms": avg_kernel_s * 1e3,

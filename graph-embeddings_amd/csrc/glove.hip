@@ -855,7 +855,7 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     if (cfg->threads < 1) return ge::fail(GE_ERR_ARG, "threads must be >= 1");
     if (cfg->mode != GE_MODE_HOGWILD && cfg->mode != GE_MODE_DETERMINISTIC) return ge::fail(GE_ERR_ARG, "invalid mode %d", cfg->mode);
     if (cfg->shuffle < GE_SHUFFLE_JAVA || cfg->shuffle > GE_SHUFFLE_NONE) return ge::fail(GE_ERR_ARG, "invalid shuffle %d", cfg->shuffle);
-    if (cfg->workers < 0) return ge::fail(GE_ERR_ARG, "workers must be >= 0");
+    if (cfg->workers < -(1 << 20)) return ge::fail(GE_ERR_ARG, "workers out of range");
     if (cfg->emb_dtype != GE_DTYPE_F32 && cfg->emb_dtype != GE_DTYPE_BF16) return ge::fail(GE_ERR_ARG, "invalid emb_dtype %d", cfg->emb_dtype);
     const bool emb16 = cfg->emb_dtype == GE_DTYPE_BF16;
     if (emb16 && (cfg->mode != GE_MODE_HOGWILD || cfg->shuffle != GE_SHUFFLE_DEVICE || cfg->opt != GE_OPT_ADAGRAD || cfg->dim % 4 != 0))
@@ -925,6 +925,9 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
         if (cfg->workers > 0) {                       // explicit worker count (tests, reproducibility)
             h->hw_workers = (int)std::min<int64_t>(cfg->workers, (int64_t)h->num_cus * 32);
             h->hw_blocks = (h->hw_workers + 3) / 4;
+        } else if (cfg->workers < 0) {                // fill the device but leave -workers wavefront slots to kernels
+            h->hw_blocks = (int)std::max<int64_t>(1, (int64_t)h->hw_blocks - (-(int64_t)cfg->workers + 3) / 4);   // running beside (collectives)
+            h->hw_workers = h->hw_blocks * 4;
         }
         // ---- hub columns --------------------------------------------------------------------------
         std::vector<int32_t> cnt((size_t)V, 0);

@@ -30,7 +30,7 @@ SYMBOLS = (
     "ge_glove_cfg_default", "ge_glove_create", "ge_glove_epoch", "ge_glove_extract_f32",
     "ge_glove_extract_f64", "ge_glove_get_state", "ge_glove_set_state", "ge_glove_device_ptr",
     "ge_glove_epoch_order", "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
-    "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_device_count",
+    "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_device_count",
 )
 
 
@@ -97,6 +97,7 @@ def lib():
     L.ge_bca_build.argtypes = [C.POINTER(Csr), C.POINTER(Csr), C.POINTER(BcaCfg), C.POINTER(vp)]
     L.ge_coo_get.argtypes = [vp, i64p, C.POINTER(i32p), C.POINTER(i32p), C.POINTER(f32p), C.POINTER(i64p), f64p]
     L.ge_coo_destroy.argtypes = [vp]; L.ge_coo_destroy.restype = None
+    L.ge_exchange_turn.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
     L.ge_last_error.argtypes = []; L.ge_last_error.restype = C.c_char_p
     L.ge_version.argtypes = []; L.ge_version.restype = C.c_char_p
     L.ge_device_count.argtypes = []; L.ge_device_count.restype = C.c_int32

@@ -117,3 +117,104 @@ class ContextSync:
             t.div_(cnt.clamp_(min=1.0))
             t.add_(o)
             o.copy_(t)
+
+    # ---- overlapped exchange: the all-reduce of step k's deltas runs under step k+1 -------------------------
+    #
+    #   take   after the local pass of step k: delta_k = table - base is narrowed into the wire buffer, a copy of it
+    #          is kept ("own"), base = table, and the all-reduces start on the backend's own stream;
+    #   land   after the local pass of step k+1: waits for them and adds what the OTHER ranks contributed,
+    #          merged_k - own_k, to the table (and to the base, so it is not taken for this rank's next delta).
+    #
+    # turn() = land what is in flight, then take; begin() = take only; finish() = land only.  The table itself is
+    # never on the wire, so the local pass may keep updating it while the exchange is in flight; a rank sees the
+    # other ranks' moves one step late (tools/multirank_sim.py: the merged model trails the synchronous exchange
+    # by about one epoch, stable).  Between turns the replicas differ by what is in flight and by the bf16
+    # rounding of their own deltas; replicate() makes them identical again.
+    #
+    # Large fp32 tables in device memory go through ONE fused pass of the HIP library per turn
+    # (ge_exchange_turn, csrc/exchange.hip: 24 B per element instead of 44 B over six torch passes); host tensors
+    # (the gloo tests) and the small bias tables use the torch ops written out below.
+
+    def _entries(self):
+        if not hasattr(self, "_ent"):
+            self._ent = ([dict(t=t, o=o, mean=False, lazy=False, work=None) for t, o in zip(self.sums, self.old_s)] +
+                         [dict(t=t, o=o, mean=False, lazy=True, work=None) for t, o in zip(self.lazy, self.old_l)] +
+                         [dict(t=t, o=o, mean=True, lazy=False, work=None) for t, o in zip(self.means, self.old_m)])
+            for e in self._ent:
+                t = e["t"]
+                narrow = self.wire == "bf16" and not e["mean"] and t.numel() >= (1 << 20)
+                e["w"] = self.torch.empty(t.shape, dtype=self.torch.bfloat16 if narrow else t.dtype, device=t.device)
+                e["own"] = self.torch.empty_like(e["w"])
+                e["cnt"] = None
+                e["fused"] = bool(narrow and t.is_cuda and t.dtype == self.torch.float32 and t.is_contiguous())
+        return self._ent
+
+    def _fused_turn(self, e, land, take):
+        from . import capi                      # the HIP library; fails loudly when it has not been built
+        t = e["t"]
+        with self.torch.cuda.device(t.device):
+            capi.check(capi.lib().ge_exchange_turn(t.data_ptr(), e["o"].data_ptr(), e["w"].data_ptr(), e["own"].data_ptr(),
+                                                   t.numel(), int(land), int(take),
+                                                   self.torch.cuda.current_stream(t.device).cuda_stream))
+
+    def _turn(self, land, take, everything=False):
+        if self.world == 1:
+            return
+        torch, dist = self.torch, self.dist
+        due = False
+        if take:
+            self.calls += 1
+            due = everything or self.calls % self.lazy_every == 0
+        for e in self._entries():
+            do_land = land and e["work"] is not None
+            do_take = take and (due or not e["lazy"])
+            if take and e["work"] is not None and not land:
+                raise RuntimeError("finish() the previous exchange first")
+            if not (do_land or do_take):
+                continue
+            t, o, w, own = e["t"], e["o"], e["w"], e["own"]
+            if do_land:
+                for x in e["work"]:
+                    x.wait()
+                e["work"] = None
+                if e["mean"]:
+                    w.div_(e["cnt"].clamp_(min=1.0))
+            if e["fused"]:
+                self._fused_turn(e, do_land, do_take)
+            else:
+                if do_land:
+                    w.sub_(own)                                         # what the other ranks contributed
+                    t.add_(w)
+                    o.add_(w)
+                if do_take:
+                    torch.sub(t, o, out=w)
+                    own.copy_(w)
+                    o.copy_(t)
+            if do_take:
+                work = []
+                if e["mean"]:
+                    e["cnt"] = own.ne(0).to(torch.float32)
+                    work.append(dist.all_reduce(e["cnt"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                work.append(dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                e["work"] = work
+
+    def begin(self, everything=False):
+        self._turn(False, True, everything)
+
+    def finish(self):
+        self._turn(True, False)
+
+    def turn(self, everything=False):
+        self._turn(True, True, everything)
+
+    def replicate(self, src=0):
+        """Ends an overlapped run: lands what is in flight, exchanges what has not been sent yet (accumulators
+        included), then every rank takes rank `src`'s replica of all tables (their remaining differences are the
+        bf16 rounding of own deltas, see above)."""
+        if self.world == 1:
+            return
+        self.turn(everything=True)
+        self.finish()
+        for e in self._entries():
+            self.dist.broadcast(e["t"], src=src, group=self.group)
+            e["o"].copy_(e["t"])

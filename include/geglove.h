@@ -125,7 +125,9 @@ typedef struct {
     int32_t hot_columns;    /* GE_HOT_* (HOGWILD mode only)                                            */
     int32_t workers;        /* HOGWILD: number of sequential workers (wavefronts); 0 = fill the device.
                                Workers pull chunks of 128 consecutive nonzeros of the epoch order from a queue
-                               and walk each chunk in stable column order; workers = 1 is fully sequential. */
+                               and walk each chunk in stable column order; workers = 1 is fully sequential.
+                               workers = -k fills the device except for k wavefront slots, which stay free for
+                               kernels running beside the epoch (the all-reduce of an overlapped exchange). */
     int32_t emb_dtype;      /* GE_DTYPE_*: storage of the focus/context rows                           */
 } ge_glove_cfg;
 
@@ -226,6 +228,19 @@ ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_b
 ge_status ge_coo_get(const ge_coo *c, int64_t *nnz, const int32_t **I, const int32_t **J,
                      const float **X, const int64_t **row_ptr, double *max);
 void ge_coo_destroy(ge_coo *c);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Multi-GPU context exchange (no counterpart in the single-JVM reference).  The context side is
+ * replicated per GPU; after a local epoch each rank all-reduces the DELTA of its replica (RCCL, by the caller:
+ * torch.distributed in geglove/parallel.py).  This entry point is the elementwise half, one pass over device
+ * memory on `stream` (asynchronous):
+ *   land != 0:  table += wire - own     `wire` holds the all-reduced sum of every rank's bf16 delta, `own` this
+ *                                        rank's part of it, so the difference is what the others contributed;
+ *   take != 0:  d = bf16(table - base) (before landing); wire = own = d; base = table (after landing).
+ * With take == 0 the landed part is added to `base` too.  wire/own are bf16 (round to nearest even), 16-byte
+ * aligned like table/base; count = elements. */
+ge_status ge_exchange_turn(float *table, float *base, uint16_t *wire, uint16_t *own, int64_t count,
+                           int32_t land, int32_t take, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 const char *ge_last_error(void);     /* message of the calling thread's last failed call */

@@ -94,3 +94,103 @@ def test_context_sync_merge_rule_math():
     np.testing.assert_array_equal(old + d0 + d1, [1.5, 2., 7.])                                   # `sums`
     cnt = (d0 != 0).astype(np.float32) + (d1 != 0)
     np.testing.assert_array_equal(old + (d0 + d1) / np.maximum(cnt, 1), [1.5, 2., 5.])            # `means`
+
+
+# ---- overlapped exchange (begin/finish): deltas of step k land after step k+1 ---------------------------------
+
+def _overlap_rank_main(rank, world, port, V, N, D, epochs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
+    si, sj, sx = parallel.shard_nonzeros(I, J, X, parallel.shard_rows(V, world, rank))
+    base = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
+    st = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in base.state().items()}
+    view = {k: t.numpy() for k, t in st.items()}
+    sync = parallel.ContextSync(sums=[st["context"].view(-1)], means=[st["cbias"]],
+                                lazy_sums=[st["gsq_context"].view(-1), st["gsq_cbias"]], lazy_every=2, wire="f32")
+    rng = np.random.default_rng(100 + rank)
+    for _ in range(epochs):
+        p = rng.permutation(len(si))
+        O.adagrad_job(D, si[p], sj[p], sx[p], xmax, O.COST_GLOVE, view)
+        sync.turn()                                     # lands the exchange started one step ago, starts this step's
+    before = {k: st[k].clone() for k in CTX}
+    sync.replicate()
+    out = {k: st[k].numpy().copy() for k in CTX}
+    q.put((rank, {k: before[k].numpy() for k in CTX}, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _overlap_model(world, V, N, D, epochs, lazy_every=2):
+    """The same run in one process with the merge written out in numpy: rank r's table after step k holds its own
+    moves up to k and the others' up to k-1."""
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
+    init = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1).state()
+    st = [{k: v.copy() for k, v in init.items()} for _ in range(world)]
+    base = [{k: st[r][k].copy() for k in CTX} for r in range(world)]
+    shards = [parallel.shard_nonzeros(I, J, X, parallel.shard_rows(V, world, r)) for r in range(world)]
+    rngs = [np.random.default_rng(100 + r) for r in range(world)]
+    flight = None
+
+    def land(fl):
+        merged, own = fl
+        for r in range(world):
+            for k in merged:
+                R = merged[k] - own[r][k]
+                st[r][k] += R
+                base[r][k] += R
+
+    def take(keys):
+        own = [{k: st[r][k] - base[r][k] for k in keys} for r in range(world)]
+        for r in range(world):
+            for k in keys:
+                base[r][k] = st[r][k].copy()
+        merged = {}
+        for k in keys:
+            total = own[0][k].copy()
+            for r in range(1, world):
+                total = total + own[r][k]
+            if k == "cbias":
+                cnt = sum((own[r][k] != 0).astype(np.float32) for r in range(world))
+                total = total / np.maximum(cnt, np.float32(1))
+            merged[k] = total
+        return merged, own
+
+    for e in range(epochs):
+        for r in range(world):
+            si, sj, sx = shards[r]
+            p = rngs[r].permutation(len(si))
+            O.adagrad_job(D, si[p], sj[p], sx[p], xmax, O.COST_GLOVE, st[r])
+        if flight is not None:
+            land(flight)
+        keys = ("context", "cbias") + (("gsq_context", "gsq_cbias") if (e + 1) % lazy_every == 0 else ())
+        flight = take(keys)
+    before = [{k: st[r][k].copy() for k in CTX} for r in range(world)]
+    land(flight)
+    land(take(CTX))
+    return before, st
+
+
+def test_overlapped_exchange_lands_one_step_late_and_replicates():
+    world, V, N, D, epochs = 2, 1200, 30000, 8, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_rank_main, args=(r, world, port, V, N, D, epochs, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = dict()
+    for _ in range(world):
+        r, before, after = q.get(timeout=300)
+        got[r] = (before, after)
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    before, final = _overlap_model(world, V, N, D, epochs)
+    for r in range(world):
+        for k in CTX:
+            # two ranks: a+b in either order is the same float, so the model is exact
+            np.testing.assert_array_equal(got[r][0][k].ravel(), before[r][k].ravel(), err_msg="rank %d %s before replicate" % (r, k))
+    for k in CTX:
+        np.testing.assert_array_equal(got[0][1][k], got[1][1][k])                  # replicas identical after replicate()
+        np.testing.assert_array_equal(got[0][1][k].ravel(), final[0][k].ravel())    # ... and equal to rank 0's merged table
+    # the two replicas differ before replicate() only by what was in flight
+    assert not np.array_equal(got[0][0]["context"], got[1][0]["context"])
