@@ -10,7 +10,7 @@ All compute goes through libgeglove.so (HIP, gfx950).  Nothing here falls back t
 from . import capi
 from .capi import GeError
 from .host import (Configuration, CooMatrix, BookmarkColoring, Adagrad, Adam, AMSGrad, createOptimizer, Optimum,
-                   GloveCost, PGloveCost, InvalidConfigurationException)
+                   GloveCost, PGloveCost, InvalidConfigurationException, SimilarityGroup, CompareGroup)
 
 __all__ = ["capi", "GeError", "Configuration", "CooMatrix", "BookmarkColoring", "Adagrad", "Adam", "AMSGrad", "createOptimizer", "Optimum",
-           "GloveCost", "PGloveCost", "InvalidConfigurationException"]
+           "GloveCost", "PGloveCost", "InvalidConfigurationException", "SimilarityGroup", "CompareGroup"]

@@ -30,7 +30,8 @@ SYMBOLS = (
     "ge_glove_cfg_default", "ge_glove_create", "ge_glove_epoch", "ge_glove_extract_f32",
     "ge_glove_extract_f64", "ge_glove_get_state", "ge_glove_set_state", "ge_glove_device_ptr",
     "ge_glove_epoch_order", "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
-    "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_device_count",
+    "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn",
+    "ge_sim_cfg_default", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_device_count",
 )
 
 
@@ -58,6 +59,16 @@ class BcaCfg(C.Structure):
     _fields_ = [("alpha", C.c_double), ("epsilon", C.c_double), ("directed", C.c_int32),
                 ("normalize", C.c_int32), ("device", C.c_int32), ("row_begin", C.c_int32),
                 ("row_end", C.c_int32)]
+
+
+class SimCfg(C.Structure):
+    _fields_ = [("method", C.c_int32), ("threshold", C.c_double), ("ngram", C.c_int32), ("smooth", C.c_double),
+                ("distance", C.c_double), ("time", C.c_int32), ("pattern", C.c_char_p), ("upper_triangle", C.c_int32),
+                ("device", C.c_int32)]
+
+
+class Strings(C.Structure):
+    _fields_ = [("count", C.c_int32), ("offset", C.POINTER(C.c_int64)), ("units", C.POINTER(C.c_uint16))]
 
 
 class GeError(RuntimeError):
@@ -97,6 +108,11 @@ def lib():
     L.ge_bca_build.argtypes = [C.POINTER(Csr), C.POINTER(Csr), C.POINTER(BcaCfg), C.POINTER(vp)]
     L.ge_coo_get.argtypes = [vp, i64p, C.POINTER(i32p), C.POINTER(i32p), C.POINTER(f32p), C.POINTER(i64p), f64p]
     L.ge_coo_destroy.argtypes = [vp]; L.ge_coo_destroy.restype = None
+    L.ge_sim_cfg_default.argtypes = [C.POINTER(SimCfg)]; L.ge_sim_cfg_default.restype = None
+    L.ge_sim_pattern_supported.argtypes = [C.c_char_p]; L.ge_sim_pattern_supported.restype = C.c_int32
+    L.ge_similarity_pairs.argtypes = [C.POINTER(Strings), i32p, i32p, C.c_int32, i32p, i32p, C.c_int32, C.POINTER(SimCfg), C.POINTER(vp)]
+    L.ge_sim_pairs_get.argtypes = [vp, i64p, C.POINTER(i32p), C.POINTER(i32p), C.POINTER(f32p)]
+    L.ge_sim_pairs_destroy.argtypes = [vp]; L.ge_sim_pairs_destroy.restype = None
     L.ge_exchange_turn.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
     L.ge_last_error.argtypes = []; L.ge_last_error.restype = C.c_char_p
     L.ge_version.argtypes = []; L.ge_version.restype = C.c_char_p

@@ -376,3 +376,89 @@ def createOptimizer(config, coMatrix, **kw):
     if m == "AMSGRAD":
         return AMSGrad(coMatrix, config, cf, **kw)
     raise ValueError("Invalid optimization method")
+
+
+# ------------------------------------------------------------------------------------------------
+# literal-similarity edges
+# ------------------------------------------------------------------------------------------------
+SIMILARITY_METHODS = ("ngram_cosine", "ngram_jaccard", "token_cosine", "token_jaccard", "jarowinkler", "levenshtein",
+                      "numeric", "date_days", "date_months", "date_years")      # Configuration.SimilarityMethod (:27-29)
+SIMILARITY_TIMES = ("backwards", "forwards", "bidirectional")                    # SimilarityGroup.Time (:184-186)
+
+
+class SimilarityGroup:
+    """Configuration.SimilarityGroup (J/util/config/Configuration.java:182-318): one `similarity:` entry of the YAML."""
+
+    def __init__(self, d):
+        self.sourcePredicate = d.get("sourcePredicate", d.get("predicate"))
+        self.targetPredicate = d.get("targetPredicate", d.get("predicate"))
+        self.method = d["method"]
+        self.threshold = float(d.get("threshold", 0.0))
+        self.ngram = int(d.get("ngram", 0))
+        self.distance = float(d.get("distance", 0.0))
+        self.smooth = float(d.get("smooth", 0.0))
+        self.pattern = d.get("pattern")
+        self.time = d.get("time")
+
+    def getMethodEnum(self):
+        m = self.method.lower()
+        if m not in SIMILARITY_METHODS:
+            raise ValueError("No enum constant SimilarityMethod." + self.method.upper())      # valueOf throws
+        return SIMILARITY_METHODS.index(m)
+
+    def getNgram(self): return 3 if self.ngram == 0 else self.ngram
+    def getSmooth(self): return 1.0 if self.smooth == 0 else self.smooth
+    def getPattern(self): return "iso" if self.pattern is None else self.pattern
+    def getTime(self): return "bidirectional" if self.time is None else self.time
+    def getTimeEnum(self): return SIMILARITY_TIMES.index(self.getTime().lower())
+
+
+class CompareGroup:
+    """CompareGroup + the CompareJob loop (J/compare/CompareGroup.java, CompareJob.java, Rdf2GrphConverter.java:127-186)
+    on the device: compare(labels) returns the (source vertex, target vertex, float similarity) triples for which the
+    reference adds its two directed edges, in job order."""
+
+    def __init__(self, group, device=0):
+        self.group = group
+        self.upperTriangle = group.sourcePredicate == group.targetPredicate       # Rdf2GrphConverter.java:51
+        self.source, self.target = [], []
+        self.device = device
+
+    def addToSource(self, vertex): self.source.append(int(vertex))
+    def addToTarget(self, vertex): self.target.append(int(vertex))
+
+    def compare(self, vertex_labels):
+        """vertex_labels: vertex id -> label (g.getVertexLabelProperty())."""
+        g = self.group
+        verts = sorted(set(self.source) | set(self.target))
+        pos = {v: k for k, v in enumerate(verts)}
+        parts = [np.frombuffer(vertex_labels[v].encode("utf-16-le"), dtype=np.uint16) for v in verts]
+        off = np.zeros(len(parts) + 1, np.int64)
+        if parts:
+            off[1:] = np.cumsum([len(x) for x in parts])
+        units = np.ascontiguousarray(np.concatenate(parts) if parts and off[-1] else np.zeros(1, np.uint16), dtype=np.uint16)
+        table = capi.Strings(len(parts), _p(off, C.c_int64), _p(units, C.c_uint16))
+        sv = np.ascontiguousarray(self.source, dtype=np.int32); tv = np.ascontiguousarray(self.target, dtype=np.int32)
+        sp = np.ascontiguousarray([pos[v] for v in self.source], dtype=np.int32)
+        tp = np.ascontiguousarray([pos[v] for v in self.target], dtype=np.int32)
+        cfg = capi.SimCfg()
+        L = capi.lib()
+        L.ge_sim_cfg_default(C.byref(cfg))
+        cfg.method = g.getMethodEnum(); cfg.threshold = g.threshold; cfg.ngram = g.getNgram(); cfg.smooth = g.getSmooth()
+        cfg.distance = g.distance; cfg.time = g.getTimeEnum()
+        cfg.pattern = None if g.getPattern() == "iso" else g.getPattern().encode()
+        cfg.upper_triangle = int(self.upperTriangle); cfg.device = self.device
+        h = C.c_void_p()
+        capi.check(L.ge_similarity_pairs(C.byref(table), _p(sp, C.c_int32), _p(sv, C.c_int32), len(sp),
+                                         _p(tp, C.c_int32), _p(tv, C.c_int32), len(tp), C.byref(cfg), C.byref(h)))
+        try:
+            n = C.c_int64(); pi = C.POINTER(C.c_int32)(); pj = C.POINTER(C.c_int32)(); ps = C.POINTER(C.c_float)()
+            capi.check(L.ge_sim_pairs_get(h, C.byref(n), C.byref(pi), C.byref(pj), C.byref(ps)))
+            k = n.value
+            i = np.ctypeslib.as_array(pi, (k,)).copy() if k else np.zeros(0, np.int32)
+            j = np.ctypeslib.as_array(pj, (k,)).copy() if k else np.zeros(0, np.int32)
+            sim = np.ctypeslib.as_array(ps, (k,)).copy() if k else np.zeros(0, np.float32)
+        finally:
+            L.ge_sim_pairs_destroy(h)
+        self.pairs = (i, j, sim)                                       # positions in source / target, as CompareResult holds them
+        return sv[i], tv[j], sim

@@ -230,6 +230,58 @@ ge_status ge_coo_get(const ge_coo *c, int64_t *nnz, const int32_t **I, const int
 void ge_coo_destroy(ge_coo *c);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Literal-similarity edges.  Replaces the compare loop of Rdf2GrphConverter.convert
+ * (J/convert/Rdf2GrphConverter.java:127-186): for one CompareGroup, CompareJob i (J/compare/CompareJob.java:33-51)
+ * walks target[startIndex..] and keeps the pairs with metric.similarity(s1, s2) >= threshold; the caller then adds the
+ * two directed edges per pair (:163-173).  Methods = Configuration.SimilarityMethod ordinals
+ * (J/util/config/Configuration.java:27-29), metrics = SimilarityGroup.toFunction (:201-227). */
+enum { GE_SIM_NGRAM_COSINE = 0, GE_SIM_NGRAM_JACCARD = 1, GE_SIM_TOKEN_COSINE = 2, GE_SIM_TOKEN_JACCARD = 3,
+       GE_SIM_JAROWINKLER = 4, GE_SIM_LEVENSHTEIN = 5, GE_SIM_NUMERIC = 6,
+       GE_SIM_DATE_DAYS = 7, GE_SIM_DATE_MONTHS = 8, GE_SIM_DATE_YEARS = 9 };
+enum { GE_TIME_BACKWARDS = 0, GE_TIME_FORWARDS = 1, GE_TIME_BIDIRECTIONAL = 2 };   /* SimilarityGroup.Time (:184-186) */
+
+typedef struct {
+    int32_t method;          /* GE_SIM_*                                                                    */
+    double  threshold;       /* SimilarityGroup.getThreshold                                                */
+    int32_t ngram;           /* getNgram (0 = 3)                                                            */
+    double  smooth;          /* getSmooth (0 = 1); Numeric's alpha                                          */
+    double  distance;        /* getDistance                                                                 */
+    int32_t time;            /* GE_TIME_* (Date* only)                                                      */
+    const char *pattern;     /* getPattern: NULL or "iso" = BASIC_ISO_DATE; else the ofPattern subset
+                                yyyy|uuuu, MM|M, dd|d, quoted text and literal characters                   */
+    int32_t upper_triangle;  /* CompareGroup.upperTriangle: source predicate == target predicate, job i starts
+                                at target i+1 (source and target must then be the same list)               */
+    int32_t device;          /* HIP device ordinal                                                          */
+} ge_sim_cfg;
+
+/* A table of java.lang.String values: string s = UTF-16 code units [offset[s], offset[s+1]) of `units`
+ * (what JNI's GetStringChars returns).  At most 1024 units per string that takes part in a comparison. */
+typedef struct {
+    int32_t         count;
+    const int64_t  *offset;  /* count + 1 ascending entries */
+    const uint16_t *units;
+} ge_strings;
+
+typedef struct ge_sim_pairs ge_sim_pairs;
+
+void ge_sim_cfg_default(ge_sim_cfg *cfg);
+/* 1 when Date* can parse with this pattern (NULL/"iso" included), 0 when it is outside the supported subset. */
+int32_t ge_sim_pattern_supported(const char *pattern);
+/* source[i] / target[j] are positions in `strings` (vertexLabels.getValueAsString of sourceNodes[i] / targetNodes[j]),
+ * source_vertex / target_vertex the vertex ids (a job skips its own vertex, CompareJob.java:38).  The result lists
+ * (i, j, (float) similarity) in job order -- i ascending, j ascending inside a job -- which is the order results
+ * arrive in with `threads: 1`.  A Numeric job that dies in String.substring (Numeric.java:36) yields nothing, as its
+ * ExecutionException does in the reference (Rdf2GrphConverter.java:176-178). */
+ge_status ge_similarity_pairs(const ge_strings *strings,
+                              const int32_t *source, const int32_t *source_vertex, int32_t n_source,
+                              const int32_t *target, const int32_t *target_vertex, int32_t n_target,
+                              const ge_sim_cfg *cfg, ge_sim_pairs **result);
+/* Host views, valid until ge_sim_pairs_destroy.  Any out pointer may be NULL. */
+ge_status ge_sim_pairs_get(const ge_sim_pairs *r, int64_t *count, const int32_t **source_pos, const int32_t **target_pos,
+                           const float **similarity);
+void ge_sim_pairs_destroy(ge_sim_pairs *r);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Multi-GPU context exchange (no counterpart in the single-JVM reference).  The context side is
  * replicated per GPU; after a local epoch each rank all-reduces the DELTA of its replica (RCCL, by the caller:
  * torch.distributed in geglove/parallel.py).  This entry point is the elementwise half, one pass over device

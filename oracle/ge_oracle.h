@@ -137,6 +137,32 @@ float geo_opt_job(int opt_kind, int iteration, int32_t D, int64_t n,
  * Java rounds HALF_UP on the shortest-repr decimal of the double. */
 int geo_format_11_6E(double v, char *buf, int buflen);
 
+/* ---- literal-similarity edges (oracle/ge_oracle_sim.c) ----
+ * Configuration.SimilarityMethod ordinals (J/util/config/Configuration.java:27-29) and SimilarityGroup.Time (:184-186). */
+enum { GEO_SIM_NGRAM_COSINE = 0, GEO_SIM_NGRAM_JACCARD = 1, GEO_SIM_TOKEN_COSINE = 2, GEO_SIM_TOKEN_JACCARD = 3,
+       GEO_SIM_JAROWINKLER = 4, GEO_SIM_LEVENSHTEIN = 5, GEO_SIM_NUMERIC = 6,
+       GEO_SIM_DATE_DAYS = 7, GEO_SIM_DATE_MONTHS = 8, GEO_SIM_DATE_YEARS = 9 };
+enum { GEO_TIME_BACKWARDS = 0, GEO_TIME_FORWARDS = 1, GEO_TIME_BIDIRECTIONAL = 2 };
+typedef struct {
+    int32_t method;        /* GEO_SIM_*                                               */
+    double  threshold;     /* SimilarityGroup.getThreshold                            */
+    int32_t ngram;         /* getNgram(): 0 in the YAML means 3                       */
+    double  smooth;        /* getSmooth(): 0 means 1 (Numeric's `alpha`)              */
+    double  distance;      /* getDistance()                                           */
+    int32_t time;          /* GEO_TIME_*                                              */
+    const char *pattern;   /* getPattern(): NULL / "iso" = BASIC_ISO_DATE             */
+} geo_sim_cfg;
+/* metric.similarity(s1, s2) on UTF-16 code units; *threw = 1 where the Java call throws (Numeric.java:35-36) */
+double  geo_sim_pair(const geo_sim_cfg *c, const uint16_t *s1, int32_t n1, const uint16_t *s2, int32_t n2, int *threw);
+double  geo_sim_jarowinkler(const uint16_t *s1, int32_t n1, const uint16_t *s2, int32_t n2);
+int32_t geo_sim_levenshtein_distance(const uint16_t *s1, int32_t n1, const uint16_t *s2, int32_t n2);
+int     geo_sim_pattern_supported(const char *pattern);
+/* CompareJob loop of one CompareGroup, jobs in order (threads: 1); returns the number of (source i, target j, sim) */
+int64_t geo_compare_group(const geo_sim_cfg *c, const int64_t *offset, const uint16_t *units,
+                          const int32_t *src, const int32_t *src_vert, int32_t n_src,
+                          const int32_t *tgt, const int32_t *tgt_vert, int32_t n_tgt, int upper_triangle,
+                          int32_t *out_src, int32_t *out_tgt, float *out_sim, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

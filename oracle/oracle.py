@@ -20,9 +20,64 @@ STATE_NAMES = ("focus", "context", "fbias", "cbias", "gsq_focus", "gsq_context",
                "m2_focus", "m2_context", "m2_fbias", "m2_cbias")
 
 
+SIM_METHODS = ("ngram_cosine", "ngram_jaccard", "token_cosine", "token_jaccard", "jarowinkler", "levenshtein", "numeric",
+               "date_days", "date_months", "date_years")          # Configuration.SimilarityMethod ordinals
+SIM_TIMES = ("backwards", "forwards", "bidirectional")
+
+
+class SimCfg(C.Structure):
+    _fields_ = [("method", C.c_int32), ("threshold", C.c_double), ("ngram", C.c_int32), ("smooth", C.c_double),
+                ("distance", C.c_double), ("time", C.c_int32), ("pattern", C.c_char_p)]
+
+
+def sim_cfg(method, threshold=0.0, ngram=3, smooth=1.0, distance=0.0, time="bidirectional", pattern=None):
+    return SimCfg(SIM_METHODS.index(method.lower()), float(threshold), int(ngram) or 3, float(smooth) or 1.0, float(distance),
+                  SIM_TIMES.index(time.lower()), None if pattern is None else pattern.encode())
+
+
+def utf16(s):
+    """java.lang.String view of a Python str: UTF-16 code units."""
+    return np.frombuffer(s.encode("utf-16-le"), dtype=np.uint16).copy() if s else np.zeros(0, np.uint16)
+
+
+def string_table(strings):
+    """(offset int64[n+1], units uint16[...]) of a list of Python strings."""
+    parts = [utf16(s) for s in strings]
+    off = np.zeros(len(parts) + 1, np.int64)
+    off[1:] = np.cumsum([len(p) for p in parts])
+    units = np.concatenate(parts) if parts and off[-1] else np.zeros(1, np.uint16)
+    return off, np.ascontiguousarray(units, dtype=np.uint16)
+
+
+def sim_pair(cfg, s1, s2):
+    """metric.similarity(s1, s2); returns (value, threw)."""
+    a, b = utf16(s1), utf16(s2)
+    a_ = np.ascontiguousarray(a if len(a) else np.zeros(1, np.uint16)); b_ = np.ascontiguousarray(b if len(b) else np.zeros(1, np.uint16))
+    threw = C.c_int(0)
+    v = lib().geo_sim_pair(C.byref(cfg), _p(a_, C.c_uint16), len(a), _p(b_, C.c_uint16), len(b), C.byref(threw))
+    return v, bool(threw.value)
+
+
+def compare_group(cfg, strings, source, target, source_vertex=None, target_vertex=None, upper_triangle=False):
+    """The CompareJob loop of one CompareGroup with threads: 1 -> (i, j, float32 similarity) arrays."""
+    off, units = string_table(strings)
+    src = np.ascontiguousarray(source, dtype=np.int32); tgt = np.ascontiguousarray(target, dtype=np.int32)
+    sv = np.ascontiguousarray(src if source_vertex is None else source_vertex, dtype=np.int32)
+    tv = np.ascontiguousarray(tgt if target_vertex is None else target_vertex, dtype=np.int32)
+    args = (C.byref(cfg), _p(off, C.c_int64), _p(units, C.c_uint16), _p(src, C.c_int32), _p(sv, C.c_int32), len(src),
+            _p(tgt, C.c_int32), _p(tv, C.c_int32), len(tgt), int(bool(upper_triangle)))
+    cap = 1 << 16
+    while True:
+        oi = np.zeros(cap, np.int32); oj = np.zeros(cap, np.int32); osim = np.zeros(cap, np.float32)
+        n = lib().geo_compare_group(*args, _p(oi, C.c_int32), _p(oj, C.c_int32), _p(osim, C.c_float), cap)
+        if n <= cap:
+            return oi[:n].copy(), oj[:n].copy(), osim[:n].copy()
+        cap = int(n)
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "ge_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("ge_oracle.c", "ge_oracle_sim.c", "ge_oracle.h")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -75,6 +130,14 @@ def lib():
                                   f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p]
     L.geo_adagrad_job.restype = C.c_float
     L.geo_format_11_6E.argtypes = [C.c_double, C.c_char_p, C.c_int]; L.geo_format_11_6E.restype = C.c_int
+    u16p = C.POINTER(C.c_uint16)
+    L.geo_sim_pair.argtypes = [C.POINTER(SimCfg), u16p, C.c_int32, u16p, C.c_int32, C.POINTER(C.c_int)]; L.geo_sim_pair.restype = C.c_double
+    L.geo_sim_jarowinkler.argtypes = [u16p, C.c_int32, u16p, C.c_int32]; L.geo_sim_jarowinkler.restype = C.c_double
+    L.geo_sim_levenshtein_distance.argtypes = [u16p, C.c_int32, u16p, C.c_int32]; L.geo_sim_levenshtein_distance.restype = C.c_int32
+    L.geo_sim_pattern_supported.argtypes = [C.c_char_p]; L.geo_sim_pattern_supported.restype = C.c_int
+    L.geo_compare_group.argtypes = [C.POINTER(SimCfg), i64p, u16p, i32p, i32p, C.c_int32, i32p, i32p, C.c_int32, C.c_int,
+                                    i32p, i32p, f32p, C.c_int64]
+    L.geo_compare_group.restype = C.c_int64
     _lib = L
     return L
 
