@@ -22,11 +22,16 @@ const char *geh_config_summary(const char *path, int do_check) {
     return g_buf.c_str();
 }
 // parses an N-Triples file with the weights of a config; writes counts and the CSR into caller buffers via a text dump
-const char *geh_graph_summary(const char *config_path, const char *nt_path) {
+static const char *graph_summary(const char *config_path, const char *nt_path, bool similarity);
+const char *geh_graph_summary(const char *config_path, const char *nt_path) { return graph_summary(config_path, nt_path, false); }
+// the same with the similarity edges of the config's `similarity:` groups (needs the GPU: ge_similarity_pairs)
+const char *geh_graph_summary_similarity(const char *config_path, const char *nt_path) { return graph_summary(config_path, nt_path, true); }
+static const char *graph_summary(const char *config_path, const char *nt_path, bool similarity) {
     try {
         const Configuration c = Configuration::load(config_path);
-        const InMemoryGraph g = read_ntriples(nt_path, c);
-        std::string s = "V=" + std::to_string(g.V) + " triples=" + std::to_string(g.triples) + " skipped=" + std::to_string(g.skipped) + "\n";
+        const InMemoryGraph g = read_ntriples(nt_path, c, similarity);
+        std::string s = "V=" + std::to_string(g.V) + " triples=" + std::to_string(g.triples) + " skipped=" + std::to_string(g.skipped) +
+                        (similarity ? " pairs=" + std::to_string(g.similarity_pairs) : std::string()) + "\n";
         for (int v = 0; v < g.V; ++v) {
             s += std::to_string(v) + "\t" + std::to_string((int)g.types[(size_t)v]) + "\t" + g.keys[(size_t)v] + "\tout:";
             for (int64_t k = g.out_ptr[(size_t)v]; k < g.out_ptr[(size_t)v + 1]; ++k) s += " " + std::to_string(g.out_idx[(size_t)k]) + "(" + java_number(g.out_w[(size_t)k], true) + ")";

@@ -21,6 +21,8 @@
 #include <filesystem>
 #include <fstream>
 #include <map>
+#include <set>
+#include <iterator>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -406,6 +408,61 @@ struct InMemoryGraph {
     std::vector<int32_t> out_idx, in_idx;
     std::vector<float> out_w, in_w;
     long long triples = 0, skipped = 0;
+    long long similarity_pairs = 0;      // "Created links for N literal pairs", summed over the groups
+};
+
+// java.lang.String view of a UTF-8 label: UTF-16 code units (malformed bytes become U+FFFD, as Java's decoder does)
+inline void utf8_to_utf16(const std::string &in, std::vector<uint16_t> &out) {
+    for (size_t i = 0; i < in.size();) {
+        const unsigned char c = (unsigned char)in[i];
+        uint32_t cp = 0xFFFD; size_t len = 1;
+        auto cont = [&](size_t k) { return i + k < in.size() && ((unsigned char)in[i + k] & 0xC0) == 0x80; };
+        if (c < 0x80) cp = c;
+        else if ((c & 0xE0) == 0xC0 && cont(1)) { cp = ((c & 0x1Fu) << 6) | ((unsigned char)in[i + 1] & 0x3Fu); len = 2; if (cp < 0x80) cp = 0xFFFD; }
+        else if ((c & 0xF0) == 0xE0 && cont(1) && cont(2)) { cp = ((c & 0x0Fu) << 12) | (((unsigned char)in[i + 1] & 0x3Fu) << 6) | ((unsigned char)in[i + 2] & 0x3Fu); len = 3; if (cp < 0x800) cp = 0xFFFD; }
+        else if ((c & 0xF8) == 0xF0 && cont(1) && cont(2) && cont(3)) {
+            cp = ((c & 0x07u) << 18) | (((unsigned char)in[i + 1] & 0x3Fu) << 12) | (((unsigned char)in[i + 2] & 0x3Fu) << 6) | ((unsigned char)in[i + 3] & 0x3Fu); len = 4;
+            if (cp < 0x10000 || cp > 0x10FFFF) cp = 0xFFFD;
+        }
+        if (cp >= 0x10000) { cp -= 0x10000; out.push_back((uint16_t)(0xD800 + (cp >> 10))); out.push_back((uint16_t)(0xDC00 + (cp & 0x3FF))); }
+        else out.push_back((uint16_t)cp);
+        i += len;
+    }
+}
+
+// One `similarity:` entry as the converter uses it: CompareGroup (J/compare/CompareGroup.java) + SimilarityGroup.toFunction
+struct CompareGroup {
+    std::string sourcePredicate, targetPredicate, pattern;
+    ge_sim_cfg cfg;
+    std::set<int32_t> source, target;        // HashSet<Integer> in the reference; ascending here (only the order of edge insertion depends on it)
+
+    static CompareGroup from(const std::map<std::string, std::string> &m) {
+        auto g = [&](const char *k, const char *def = "") { auto it = m.find(k); return it == m.end() ? std::string(def) : it->second; };
+        CompareGroup c;
+        ge_sim_cfg_default(&c.cfg);
+        c.sourcePredicate = g("sourcePredicate"); c.targetPredicate = g("targetPredicate");
+        std::string method = g("method"), up = method;
+        for (auto &ch : up) ch = (char)std::toupper((unsigned char)ch);
+        static const char *const names[] = {"NGRAM_COSINE", "NGRAM_JACCARD", "TOKEN_COSINE", "TOKEN_JACCARD", "JAROWINKLER", "LEVENSHTEIN",
+                                            "NUMERIC", "DATE_DAYS", "DATE_MONTHS", "DATE_YEARS"};      // Configuration.java:27-29
+        int found = -1;
+        for (int k = 0; k < 10; ++k) if (up == names[k]) found = k;
+        if (found < 0) throw std::runtime_error("No enum constant org.uu.nl.embedding.util.config.Configuration.SimilarityMethod." + up);   // valueOf
+        c.cfg.method = found;
+        c.cfg.threshold = std::strtod(g("threshold", "0").c_str(), nullptr);
+        c.cfg.ngram = std::atoi(g("ngram", "0").c_str());
+        c.cfg.smooth = std::strtod(g("smooth", "0").c_str(), nullptr);
+        c.cfg.distance = std::strtod(g("distance", "0").c_str(), nullptr);
+        std::string t = g("time", "bidirectional"); for (auto &ch : t) ch = (char)std::toupper((unsigned char)ch);
+        if (t == "BACKWARDS") c.cfg.time = GE_TIME_BACKWARDS; else if (t == "FORWARDS") c.cfg.time = GE_TIME_FORWARDS;
+        else if (t == "BIDIRECTIONAL") c.cfg.time = GE_TIME_BIDIRECTIONAL;
+        else throw std::runtime_error("No enum constant org.uu.nl.embedding.util.config.Configuration.SimilarityGroup.Time." + t);
+        c.pattern = g("pattern", "iso");
+        if (found >= GE_SIM_DATE_DAYS && !ge_sim_pattern_supported(c.pattern.c_str()))
+            throw InvalidConfigurationException("date pattern '" + c.pattern + "' is outside the supported subset (iso, or yyyy/uuuu MM/M dd/d with literals)");
+        c.cfg.upper_triangle = c.sourcePredicate == c.targetPredicate;           // Rdf2GrphConverter.java:51
+        return c;
+    }
 };
 
 namespace detail {
@@ -425,7 +482,17 @@ inline bool read_term(const std::string &l, size_t &pos, Term &t) {
     if (l[pos] == '"') {
         std::string lex; size_t e = pos + 1;
         while (e < l.size() && l[e] != '"') {
-            if (l[e] == '\\' && e + 1 < l.size()) { const char c = l[e + 1]; lex.push_back(c == 'n' ? '\n' : c == 't' ? '\t' : c == 'r' ? '\r' : c); e += 2; }
+            if (l[e] == '\\' && e + 1 < l.size() && (l[e + 1] == 'u' || l[e + 1] == 'U')) {      // \uXXXX / \UXXXXXXXX
+                const size_t nd = l[e + 1] == 'u' ? 4 : 8;
+                if (e + 2 + nd > l.size()) return false;
+                const unsigned long cp = std::strtoul(l.substr(e + 2, nd).c_str(), nullptr, 16);
+                if (cp < 0x80) lex.push_back((char)cp);
+                else if (cp < 0x800) { lex.push_back((char)(0xC0 | (cp >> 6))); lex.push_back((char)(0x80 | (cp & 0x3F))); }
+                else if (cp < 0x10000) { lex.push_back((char)(0xE0 | (cp >> 12))); lex.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); lex.push_back((char)(0x80 | (cp & 0x3F))); }
+                else { lex.push_back((char)(0xF0 | (cp >> 18))); lex.push_back((char)(0x80 | ((cp >> 12) & 0x3F))); lex.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); lex.push_back((char)(0x80 | (cp & 0x3F))); }
+                e += 2 + nd;
+            }
+            else if (l[e] == '\\' && e + 1 < l.size()) { const char c = l[e + 1]; lex.push_back(c == 'n' ? '\n' : c == 't' ? '\t' : c == 'r' ? '\r' : c); e += 2; }
             else lex.push_back(l[e++]);
         }
         if (e >= l.size()) return false;
@@ -460,7 +527,10 @@ inline void edges_to_csr(int32_t V, const std::vector<int32_t> &src, const std::
     for (int32_t v = 0; v < V; ++v) ptr[(size_t)v + 1] += ptr[(size_t)v];
 }
 
-inline InMemoryGraph read_ntriples(const std::string &path, const Configuration &cfg) {
+// similarity = true also runs the compare loop of Rdf2GrphConverter.convert (:127-186) on the device (ge_similarity_pairs)
+// and adds, per matching pair, the two directed edges weighted with the similarity (:163-173).
+inline InMemoryGraph read_ntriples(const std::string &path, const Configuration &cfg, bool similarity = false, int device = 0,
+                                   void (*log)(const std::string &) = nullptr) {
     std::ifstream f(path);
     if (!f) throw std::runtime_error("Cannot read graph file " + path);
     const std::string ext = path.size() > 3 ? path.substr(path.rfind('.') == std::string::npos ? 0 : path.rfind('.')) : "";
@@ -473,6 +543,12 @@ inline InMemoryGraph read_ntriples(const std::string &path, const Configuration 
     const bool weighting = cfg.usingWeights();
     for (auto &w : cfg.weights) weight[w.first] = w.second;
     std::vector<int32_t> src, dst; std::vector<float> wt;
+    std::vector<CompareGroup> groups;
+    std::unordered_map<std::string, size_t> sourceGroups, targetGroups;               // predicate -> group (:41-56; a later entry replaces an earlier one)
+    if (similarity) {
+        for (auto &m : cfg.similarity) groups.push_back(CompareGroup::from(m));
+        for (size_t k = 0; k < groups.size(); ++k) { sourceGroups[groups[k].sourcePredicate] = k; targetGroups[groups[k].targetPredicate] = k; }
+    }
     auto addVertex = [&](const std::string &pred, const detail::Term &n) -> int32_t {     // Rdf2GrphConverter.addVertex
         if (n.type != LITERAL) {
             auto it = vertexMap.find((n.type == BLANK ? "_:" : "") + n.text);
@@ -503,6 +579,40 @@ inline InMemoryGraph read_ntriples(const std::string &path, const Configuration 
         }
         const int32_t si = addVertex(p.text, s), oi = addVertex(p.text, o);
         src.push_back(si); dst.push_back(oi); wt.push_back(w);
+        if (!groups.empty()) {                                                       // :100-110, the OBJECT joins the groups of its predicate
+            auto a = sourceGroups.find(p.text); if (a != sourceGroups.end()) groups[a->second].source.insert(oi);
+            auto b = targetGroups.find(p.text); if (b != targetGroups.end()) groups[b->second].target.insert(oi);
+        }
+    }
+    for (auto &entry : sourceGroups) {                                               // :127-186
+        CompareGroup &grp = groups[entry.second];
+        if (log) log("Processing similarities for predicate " + entry.first);
+        std::vector<int32_t> verts(grp.source.begin(), grp.source.end());
+        { std::vector<int32_t> t(grp.target.begin(), grp.target.end()), u; std::set_union(verts.begin(), verts.end(), t.begin(), t.end(), std::back_inserter(u)); verts.swap(u); }
+        std::vector<int64_t> offset(1, 0); std::vector<uint16_t> units;
+        std::unordered_map<int32_t, int32_t> pos;
+        for (int32_t v : verts) { pos[v] = (int32_t)offset.size() - 1; utf8_to_utf16(g.keys[(size_t)v], units); offset.push_back((int64_t)units.size()); }
+        if (units.empty()) units.push_back(0);
+        std::vector<int32_t> sv(grp.source.begin(), grp.source.end()), tv(grp.target.begin(), grp.target.end()), sp, tp;
+        for (int32_t v : sv) sp.push_back(pos[v]);
+        for (int32_t v : tv) tp.push_back(pos[v]);
+        ge_strings table{(int32_t)verts.size(), offset.data(), units.data()};
+        ge_sim_cfg c = grp.cfg;
+        c.pattern = grp.pattern == "iso" ? nullptr : grp.pattern.c_str();
+        c.device = device;
+        ge_sim_pairs *res = nullptr;
+        check(ge_similarity_pairs(&table, sp.data(), sv.data(), (int32_t)sp.size(), tp.data(), tv.data(), (int32_t)tp.size(), &c, &res));
+        int64_t n = 0; const int32_t *pi = nullptr, *pj = nullptr; const float *ps = nullptr;
+        const ge_status st = ge_sim_pairs_get(res, &n, &pi, &pj, &ps);
+        if (st != GE_OK) { ge_sim_pairs_destroy(res); check(st); }
+        for (int64_t k = 0; k < n; ++k) {
+            const int32_t vert = sv[(size_t)pi[k]], other = tv[(size_t)pj[k]];
+            src.push_back(vert); dst.push_back(other); wt.push_back(ps[k]);          // e1 = vert -> otherVert
+            src.push_back(other); dst.push_back(vert); wt.push_back(ps[k]);          // e2 = otherVert -> vert
+        }
+        ge_sim_pairs_destroy(res);
+        g.similarity_pairs += n;
+        if (log) log("Created links for " + std::to_string(n) + " literal pairs");
     }
     edges_to_csr(g.V, src, dst, wt, g.out_ptr, g.out_idx, g.out_w);
     edges_to_csr(g.V, dst, src, wt, g.in_ptr, g.in_idx, g.in_w);

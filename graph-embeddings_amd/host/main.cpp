@@ -28,8 +28,6 @@ static void progress(int iteration, double cost, double diff) {
 static void runProgram(const Configuration &config) {                       // J/Main.java:29-78
     for (auto &l : config.banner()) log_info("Graph Embeddings", l);
     for (auto &k : config.ignored_keys) log_info("Configuration", "ignoring key not known to this revision's bean: " + k);
-    if (config.usingSimilarity())
-        log_info("Configuration", "similarity edges are not generated by this build (literal matching is outside the device path); running without them");
     std::string outFileName = config.output.name;
     if (outFileName.empty()) outFileName = createFileName(config);
     log_info("Graph Embeddings", "Writing files with prefix: " + outFileName);
@@ -40,7 +38,9 @@ static void runProgram(const Configuration &config) {                       // J
         matrix.reset(new StoredCooMatrix(config.device.load_coo));
         log_info("BookmarkColoring", "loaded COO checkpoint " + config.device.load_coo);
     } else {
-        graph.reset(new InMemoryGraph(read_ntriples(config.graph, config)));
+        if (!config.usingSimilarity()) log_info("Rdf2GrphConverter", "Partial matching is disabled, no edges between similar literals are added");
+        graph.reset(new InMemoryGraph(read_ntriples(config.graph, config, true, config.device.id,
+                                                    [](const std::string &m) { log_info("Rdf2GrphConverter", m); })));
         char b[200];
         std::snprintf(b, sizeof b, "Skipped %lld unweighted triples (%.2f %%)", graph->skipped,
                       graph->triples ? 100.0 * (double)graph->skipped / (double)graph->triples : 0.0);

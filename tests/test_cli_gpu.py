@@ -14,6 +14,7 @@ from geglove import synth
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(REPO, "graph-embeddings_amd", "bin", "geglove")
+GOLD = os.path.join(REPO, "tests", "golden")
 
 
 def _graph_from_host():
@@ -99,3 +100,74 @@ def test_cli_coo_checkpoint_and_other_optimisers(gpu, tmp_path):
     (cwd / "c.yml").write_text(base.replace("method: adagrad", "method: adam"))
     r = subprocess.run([EXE, "-c", "c.yml"], cwd=cwd, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and os.path.exists(cwd / "out" / "tiny_pglove_partial_directed_0.1_0.001_adam_pca_8.vectors.tsv"), r.stderr
+
+
+def test_host_ingest_adds_the_similarity_edges(gpu):
+    """C++ host ingest with `similarity:` groups (Rdf2GrphConverter.convert :41-56, :100-110, :127-186) against the
+    oracle's compare loop run on the vertex labels of the same graph."""
+    L = C.CDLL(os.path.join(REPO, "graph-embeddings_amd", "lib", "libgehost.so"))
+    for f in ("geh_graph_summary", "geh_graph_summary_similarity", "geh_java_float"):
+        getattr(L, f).restype = C.c_char_p
+    L.geh_java_float.argtypes = [C.c_float]
+    cfg, nt = os.path.join(GOLD, "similar.config.yml").encode(), os.path.join(GOLD, "similar.nt").encode()
+
+    def parse(text):
+        lines = text.decode().splitlines()
+        assert lines[0] == "OK", text
+        out = {}
+        for l in lines[2:]:
+            v, typ, key, outs, _ = l.split("\t")
+            out[int(v)] = (key, dict((int(e.split("(")[0]), e.split("(")[1][:-1]) for e in outs.split()[1:]))
+        return lines[1], out
+
+    head0, plain = parse(L.geh_graph_summary(cfg, nt))
+    head1, full = parse(L.geh_graph_summary_similarity(cfg, nt))
+    labels = {v: k for v, (k, _) in plain.items()}
+    ids = {k: v for v, k in labels.items()}
+    assert sum(k == "Renée de Vries" for k in labels.values()) == 1                # "Ren\\u00E9e" is decoded and merges with the UTF-8 spelling
+    objects = {}                                                                    # predicate -> object vertices, from the fixture itself
+    literal_vertex = {}                                                             # (predicate, label) -> vertex: literals merge per predicate
+    for line in open(nt.decode(), encoding="utf-8"):
+        if line.startswith("#") or not line.strip():
+            continue
+        s, p, o = line.rstrip(" .\n").split(" ", 2)
+        p = p.strip("<>")
+        if o.startswith('"'):
+            lex = re.sub(r"\\u([0-9A-Fa-f]{4})", lambda m: chr(int(m.group(1), 16)), o[1:o.rindex('"')])
+            suffix = o[o.rindex('"') + 1:]
+            key = lex + ("^^" + suffix[3:-1] if suffix.startswith("^^") else suffix)
+            cands = [v for v, k in labels.items() if k == key]
+        else:
+            cands = [v for v, k in labels.items() if k == o.strip("<>")]
+        # literals merge per predicate: several vertices may carry the label; the right one has an in-edge from s
+        sv = [v for v, k in labels.items() if k == s.strip("<>")][0]
+        if o.startswith('"'):                                                       # ids are handed out in file order
+            if (p, key) not in literal_vertex:
+                literal_vertex[(p, key)] = min(v for v in cands if v not in literal_vertex.values())
+            ov = literal_vertex[(p, key)]
+        else:
+            ov = cands[0]
+        assert ov in plain[sv][1]
+        objects.setdefault(p, set()).add(ov)
+    groups = [("http://xmlns.com/foaf/0.1/name", "http://xmlns.com/foaf/0.1/name", O.sim_cfg("jarowinkler", 0.9)),
+              ("http://ex.org/altName", "http://purl.org/dc/elements/1.1/creator", O.sim_cfg("levenshtein", 0.1)),
+              ("http://purl.org/dc/elements/1.1/title", "http://purl.org/dc/elements/1.1/title", O.sim_cfg("token_jaccard", 0.4)),
+              ("http://ex.org/year", "http://ex.org/year", O.sim_cfg("numeric", 0.5, smooth=0.5))]
+    expected = {v: dict(e) for v, (_, e) in plain.items()}
+    pairs = 0
+    for sp, tp, c in groups:
+        src, tgt = sorted(objects[sp]), sorted(objects[tp])
+        verts = sorted(set(src) | set(tgt))
+        pos = {v: k for k, v in enumerate(verts)}
+        i, j, sim = O.compare_group(c, [labels[v] for v in verts], [pos[v] for v in src], [pos[v] for v in tgt], src, tgt, upper_triangle=sp == tp)
+        pairs += len(i)
+        for a, b, w in zip(i, j, sim):
+            va, vb = src[a], tgt[b]
+            expected[va].setdefault(vb, L.geh_java_float(float(w)).decode())       # an existing edge keeps its weight (first edge wins)
+            expected[vb].setdefault(va, L.geh_java_float(float(w)).decode())
+    assert pairs >= 6
+    assert head1 == head0 + " pairs=%d" % pairs
+    assert {v: e for v, (_, e) in full.items()} == expected
+    # spot checks a reader can follow: the two spellings of the same name are linked, equal names on two predicates are not merged
+    a, b = ids["Jan Jansen"], ids["Jan Janssen"]
+    assert b in full[a][1] and a in full[b][1] and full[a][1][b] == full[b][1][a]
