@@ -9,6 +9,7 @@
  */
 #include <jni.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "geglove.h"
 
 static void throw_ge(JNIEnv *env, ge_status st) {
@@ -114,4 +115,67 @@ JNIEXPORT void JNICALL Java_org_uu_nl_embedding_hip_Native_cooCopy(JNIEnv *env, 
 JNIEXPORT void JNICALL Java_org_uu_nl_embedding_hip_Native_cooDestroy(JNIEnv *env, jclass cls, jlong coo) {
     (void)env; (void)cls;
     ge_coo_destroy((ge_coo *)(intptr_t)coo);
+}
+
+/* long similarityPairs(String[] labels, int[] source, int[] sourceVertex, int[] target, int[] targetVertex,
+ *                      int method, double threshold, int ngram, double smooth, double distance, int time, String pattern,
+ *                      boolean upperTriangle, int device)
+ * labels[k] = vertexLabels.getValueAsString(...) of every vertex in the group; source/target index into labels.
+ * Replaces the CompareJob loop of Rdf2GrphConverter.convert (:127-186). */
+JNIEXPORT jlong JNICALL Java_org_uu_nl_embedding_hip_Native_similarityPairs(
+        JNIEnv *env, jclass cls, jobjectArray labels, jintArray source, jintArray sourceVertex, jintArray target, jintArray targetVertex,
+        jint method, jdouble threshold, jint ngram, jdouble smooth, jdouble distance, jint time, jstring pattern,
+        jboolean upperTriangle, jint device) {
+    (void)cls;
+    const jsize count = (*env)->GetArrayLength(env, labels);
+    int64_t *offset = (int64_t *)malloc(sizeof(int64_t) * ((size_t)count + 1));
+    offset[0] = 0;
+    for (jsize k = 0; k < count; ++k) {
+        jstring s = (jstring)(*env)->GetObjectArrayElement(env, labels, k);
+        offset[k + 1] = offset[k] + (*env)->GetStringLength(env, s);          /* UTF-16 code units, as String.length() */
+        (*env)->DeleteLocalRef(env, s);
+    }
+    uint16_t *units = (uint16_t *)malloc(sizeof(uint16_t) * (size_t)(offset[count] + 1));
+    for (jsize k = 0; k < count; ++k) {
+        jstring s = (jstring)(*env)->GetObjectArrayElement(env, labels, k);
+        (*env)->GetStringRegion(env, s, 0, (jsize)(offset[k + 1] - offset[k]), (jchar *)(units + offset[k]));
+        (*env)->DeleteLocalRef(env, s);
+    }
+    ge_strings table = {count, offset, units};
+    ge_sim_cfg cfg;
+    ge_sim_cfg_default(&cfg);
+    cfg.method = method; cfg.threshold = threshold; cfg.ngram = ngram; cfg.smooth = smooth; cfg.distance = distance; cfg.time = time;
+    const char *pat = pattern ? (*env)->GetStringUTFChars(env, pattern, NULL) : NULL;
+    cfg.pattern = pat; cfg.upper_triangle = upperTriangle ? 1 : 0; cfg.device = device;
+    const jsize ns = (*env)->GetArrayLength(env, source), nt = (*env)->GetArrayLength(env, target);
+    jint *ps = (*env)->GetIntArrayElements(env, source, NULL), *psv = (*env)->GetIntArrayElements(env, sourceVertex, NULL);
+    jint *pt = (*env)->GetIntArrayElements(env, target, NULL), *ptv = (*env)->GetIntArrayElements(env, targetVertex, NULL);
+    ge_sim_pairs *res = NULL;
+    ge_status st = ge_similarity_pairs(&table, (const int32_t *)ps, (const int32_t *)psv, ns, (const int32_t *)pt, (const int32_t *)ptv, nt, &cfg, &res);
+    (*env)->ReleaseIntArrayElements(env, source, ps, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, sourceVertex, psv, JNI_ABORT);
+    (*env)->ReleaseIntArrayElements(env, target, pt, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, targetVertex, ptv, JNI_ABORT);
+    if (pat) (*env)->ReleaseStringUTFChars(env, pattern, pat);
+    free(offset); free(units);
+    if (st != GE_OK) { throw_ge(env, st); return 0; }
+    return (jlong)(intptr_t)res;
+}
+
+/* long pairsCount(long pairs);  void pairsCopy(long pairs, int[] sourcePos, int[] targetPos, float[] similarity);  void pairsDestroy(long pairs) */
+JNIEXPORT jlong JNICALL Java_org_uu_nl_embedding_hip_Native_pairsCount(JNIEnv *env, jclass cls, jlong pairs) {
+    (void)env; (void)cls;
+    int64_t n = 0;
+    ge_sim_pairs_get((const ge_sim_pairs *)(intptr_t)pairs, &n, NULL, NULL, NULL);
+    return n;
+}
+JNIEXPORT void JNICALL Java_org_uu_nl_embedding_hip_Native_pairsCopy(JNIEnv *env, jclass cls, jlong pairs, jintArray sourcePos, jintArray targetPos, jfloatArray similarity) {
+    (void)cls;
+    int64_t n = 0; const int32_t *pi, *pj; const float *ps;
+    ge_sim_pairs_get((const ge_sim_pairs *)(intptr_t)pairs, &n, &pi, &pj, &ps);
+    (*env)->SetIntArrayRegion(env, sourcePos, 0, (jsize)n, (const jint *)pi);
+    (*env)->SetIntArrayRegion(env, targetPos, 0, (jsize)n, (const jint *)pj);
+    (*env)->SetFloatArrayRegion(env, similarity, 0, (jsize)n, ps);
+}
+JNIEXPORT void JNICALL Java_org_uu_nl_embedding_hip_Native_pairsDestroy(JNIEnv *env, jclass cls, jlong pairs) {
+    (void)env; (void)cls;
+    ge_sim_pairs_destroy((ge_sim_pairs *)(intptr_t)pairs);
 }
