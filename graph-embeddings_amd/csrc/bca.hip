@@ -550,7 +550,12 @@ ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_b
     int64_t hc = 2048;
     while (hc < 4 * std::min<int64_t>(V, 256)) hc <<= 1;
     int64_t pool_cap = std::max<int64_t>((int64_t)n_rows * 128, 1 << 16);
-    if (const char *e = std::getenv("GE_BCA_POOL")) pool_cap = std::max<int64_t>(64, std::atoll(e));
+    // Large builds size the pool from a sample first: 2048 evenly spaced bookmarks are run with an empty pool (every
+    // row reports its size, none is stored), the mean row size + 25 % decides.  < 1 % extra work instead of re-running
+    // the rows a wrong guess leaves out.
+    bool sampled = n_rows <= 16384;
+    if (const char *e = std::getenv("GE_BCA_POOL")) { pool_cap = std::max<int64_t>(64, std::atoll(e)); sampled = true; }
+    int32_t *d_sample = nullptr; int32_t n_sample = 0;
     if (const char *e = std::getenv("GE_BCA_TABLE")) hc = std::max<int64_t>(64, std::atoll(e));
     int32_t *d_pJ = nullptr; float *d_pX = nullptr; char *d_work = nullptr;
     std::vector<int32_t> h_n((size_t)n_rows);
@@ -570,6 +575,30 @@ ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_b
         if (d_pJ) { (void)hipFree(d_pJ); d_pJ = nullptr; }
         if (d_pX) { (void)hipFree(d_pX); d_pX = nullptr; }
         hipError_t e1 = hipMalloc((void **)&d_work, (size_t)(n_waves * stride));
+        if (e1 == hipSuccess && !sampled) {
+            if (!d_sample) {
+                n_sample = 2048;
+                std::vector<int32_t> rows((size_t)n_sample);
+                for (int32_t k = 0; k < n_sample; ++k) rows[(size_t)k] = (int32_t)((int64_t)k * n_rows / n_sample);
+                if (hipMalloc((void **)&d_sample, sizeof(int32_t) * (size_t)n_sample) != hipSuccess) { (void)hipFree(d_work); return ge::fail(GE_ERR_OOM, "device allocation failed for the BCA sample"); }
+                dev.keep(d_sample);
+                if (hipMemcpy(d_sample, rows.data(), sizeof(int32_t) * (size_t)n_sample, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_work); return ge::fail(GE_ERR_HIP, "BCA sample upload failed"); }
+            }
+            p.hc = (int32_t)hc; p.hc_log2 = hl; p.ac = (int32_t)ac; p.work = d_work; p.work_stride = stride;
+            p.outJ = nullptr; p.outX = nullptr; p.out_cap = 0; p.redo = d_sample; p.n_jobs = n_sample;
+            hipError_t e = hipMemset(d_ctr, 0, 32);
+            if (e == hipSuccess) { hipLaunchKernelGGL(k_bca, dim3((unsigned)std::min<int64_t>(n_waves, n_sample)), dim3(64), 0, 0, p); e = hipGetLastError(); }
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+            unsigned long long h_s[4] = {0, 0, 0, 0};
+            if (e == hipSuccess) e = hipMemcpy(h_s, d_ctr, 32, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { (void)hipFree(d_work); return ge::fail(GE_ERR_HIP, "BCA sample pass failed: %s", hipGetErrorString(e)); }
+            const int32_t st = (int32_t)(h_s[2] & 0xFFFFFFFFull);
+            if (st == 1) { hc *= 4; continue; }
+            if (st == 2) { ac = std::min<int64_t>(ac * 4, (int64_t)V + 64); continue; }
+            const double mean = (double)h_s[0] / (double)n_sample;           // pool_used counted every sampled row
+            pool_cap = std::max<int64_t>(1 << 16, (int64_t)(mean * 1.25 * (double)n_rows) + 65536);
+            sampled = true;
+        }
         hipError_t e2 = hipMalloc((void **)&d_pJ, sizeof(int32_t) * (size_t)pool_cap);
         hipError_t e3 = hipMalloc((void **)&d_pX, sizeof(float) * (size_t)pool_cap);
         if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
