@@ -80,6 +80,24 @@ class GeError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7) and its
+    libraries ask for it by file name, so they load it even when /opt/rocm's copy is already in the process -- and
+    the second runtime then sees no GPU ("No HIP GPUs are available").  The other order is fine: libgeglove.so asks
+    for the SONAME and takes whichever copy is loaded.  So when torch is installed (the multi-GPU path and some
+    tests use it in the same process) its copy is mapped first, without importing torch."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Loads libgeglove.so; raises (loudly) when the HIP library has not been built."""
     global _lib
@@ -88,6 +106,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("libgeglove.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C graph-embeddings_amd/csrc`" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     i32p, i64p, f32p, f64p = (C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float), C.POINTER(C.c_double))
     vp = C.c_void_p

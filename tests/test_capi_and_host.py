@@ -69,6 +69,7 @@ def test_no_cpu_fallback_without_a_device():
 # ---------------------------------------------------------------- C++ host (libgehost.so)
 @pytest.fixture(scope="module")
 def host():
+    capi._share_hip_runtime_with_torch()            # libgehost.so pulls in libgeglove.so: same rule as capi.lib()
     L = C.CDLL(os.path.join(REPO, "graph-embeddings_amd", "lib", "libgehost.so"))
     for f in ("geh_format_11_6E", "geh_java_double", "geh_java_float", "geh_config_summary", "geh_graph_summary"):
         getattr(L, f).restype = C.c_char_p
