@@ -137,9 +137,14 @@ def main():
             ptr, cnt = opt.device_ptr(name)
             return torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=dev)
 
-        sync = parallel.ContextSync(sums=[wrap("context")], means=[wrap("cbias")],
-                                    lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=args.accum_sync_every,
-                                    wire=args.wire)
+        if args.dtype == "bf16":       # context rows: bf16 table + fp32 master rows of this rank's hub columns
+            sync = parallel.ContextSync(sums=[], means=[wrap("cbias")], bf16_tables=[parallel.Bf16Context(opt, dev)],
+                                        lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=args.accum_sync_every,
+                                        wire=args.wire)
+        else:
+            sync = parallel.ContextSync(sums=[wrap("context")], means=[wrap("cbias")],
+                                        lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=args.accum_sync_every,
+                                        wire=args.wire)
 
     def step(it):
         c = opt.epoch(it)

@@ -488,7 +488,7 @@ double java_math_max(double a, double b) {
 
 extern "C" {
 
-ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_bca_cfg *cfg, ge_coo **result) {
+static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_bca_cfg *cfg, ge_coo **result) {
     if (!result) return ge::fail(GE_ERR_ARG, "result is null");
     *result = nullptr;
     if (!out_nbrs || !in_nbrs || !cfg) return ge::fail(GE_ERR_ARG, "null argument");
@@ -704,5 +704,9 @@ ge_status ge_coo_get(const ge_coo *c, int64_t *nnz, const int32_t **I, const int
 }
 
 void ge_coo_destroy(ge_coo *c) { delete c; }
+
+ge_status ge_bca_build(const ge_csr *out_nbrs, const ge_csr *in_nbrs, const ge_bca_cfg *cfg, ge_coo **result) {
+    GE_GUARD(ge_bca_build_impl(out_nbrs, in_nbrs, cfg, result));
+}
 
 }  // extern "C"

@@ -4,6 +4,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
+#include <exception>
+#include <new>
 #include "../../include/geglove.h"
 
 namespace ge {
@@ -24,6 +26,13 @@ inline ge_status fail(ge_status code, const char *fmt, ...) {
                             "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
                             __FILE__, __LINE__);                                         \
     } while (0)
+
+// No C++ exception crosses the C ABI: entry points whose bodies allocate on the host run as  GE_GUARD(name_impl(args)).
+#define GE_GUARD(call)                                                                                     \
+    try { return (call); }                                                                                  \
+    catch (const std::bad_alloc &) { return ge::fail(GE_ERR_OOM, "host allocation failed"); }              \
+    catch (const std::exception &e_) { return ge::fail(GE_ERR_STATE, "internal error: %s", e_.what()); }   \
+    catch (...) { return ge::fail(GE_ERR_STATE, "internal error"); }
 
 // Selects the device and verifies it is gfx950 (there is no fallback path).
 ge_status select_device(int device);

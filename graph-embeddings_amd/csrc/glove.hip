@@ -839,7 +839,7 @@ void ge_glove_cfg_default(ge_glove_cfg *cfg) {
     cfg->shuffle = GE_SHUFFLE_DEVICE;
 }
 
-ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32_t *J, const float *X,
+static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I, const int32_t *J, const float *X,
                           ge_glove **out) {
     if (!out) return ge::fail(GE_ERR_ARG, "out is null");
     *out = nullptr;
@@ -1094,7 +1094,7 @@ ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32
     return GE_OK;
 }
 
-ge_status ge_glove_epoch(ge_glove *h, int32_t iteration, double *cost_sum) {
+static ge_status ge_glove_epoch_impl(ge_glove *h, int32_t iteration, double *cost_sum) {
     ge_status st = check_handle(h);
     if (st != GE_OK) return st;
     const int64_t N = h->cfg.nnz;
@@ -1249,6 +1249,17 @@ ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *
     return GE_OK;
 }
 
+ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out) {
+    if (!h || !out) return ge::fail(GE_ERR_ARG, "null argument");
+    out->table = h->tab[GE_STATE_CONTEXT];
+    out->dtype = h->emb16 ? GE_DTYPE_BF16 : GE_DTYPE_F32;
+    out->hub_rows = h->emb16 ? h->hub32 : nullptr;
+    out->hub_index = h->emb16 ? h->dhub_index : nullptr;
+    out->n_hub = h->emb16 ? h->n_hub : 0;
+    out->vocab_size = h->cfg.vocab_size; out->dim = h->cfg.dim;
+    return GE_OK;
+}
+
 ge_status ge_glove_get_perm(ge_glove *h, int32_t *out, int64_t count) {
     if (!h || !out) return ge::fail(GE_ERR_ARG, "null argument");
     if (h->cfg.shuffle != GE_SHUFFLE_JAVA) return ge::fail(GE_ERR_STATE, "no permutation array unless shuffle == GE_SHUFFLE_JAVA");
@@ -1257,7 +1268,7 @@ ge_status ge_glove_get_perm(ge_glove *h, int32_t *out, int64_t count) {
     return GE_OK;
 }
 
-ge_status ge_glove_epoch_order(ge_glove *h, int32_t iteration, int32_t *out, int64_t count) {
+static ge_status ge_glove_epoch_order_impl(ge_glove *h, int32_t iteration, int32_t *out, int64_t count) {
     if (!h || !out) return ge::fail(GE_ERR_ARG, "null argument");
     if (h->cfg.mode != GE_MODE_HOGWILD) return ge::fail(GE_ERR_STATE, "epoch order is defined for GE_MODE_HOGWILD handles");
     const int64_t N = h->cfg.nnz;
@@ -1330,5 +1341,12 @@ void ge_glove_destroy(ge_glove *h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
 }
+
+// ---- guarded entry points (bodies above allocate on the host) ----
+ge_status ge_glove_create(const ge_glove_cfg *cfg, const int32_t *I, const int32_t *J, const float *X, ge_glove **out) {
+    GE_GUARD(ge_glove_create_impl(cfg, I, J, X, out));
+}
+ge_status ge_glove_epoch(ge_glove *h, int32_t iteration, double *cost_sum) { GE_GUARD(ge_glove_epoch_impl(h, iteration, cost_sum)); }
+ge_status ge_glove_epoch_order(ge_glove *h, int32_t iteration, int32_t *out, int64_t count) { GE_GUARD(ge_glove_epoch_order_impl(h, iteration, out, count)); }
 
 }  // extern "C"

@@ -21,6 +21,7 @@
 #include <cctype>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -450,9 +451,9 @@ int32_t ge_sim_pattern_supported(const char *pattern) {
     return DateFormat::compile(pattern, f) ? 1 : 0;
 }
 
-ge_status ge_similarity_pairs(const ge_strings *strings, const int32_t *src, const int32_t *src_vert, int32_t n_src,
-                              const int32_t *tgt, const int32_t *tgt_vert, int32_t n_tgt,
-                              const ge_sim_cfg *cfg, ge_sim_pairs **result) {
+static ge_status similarity_pairs_impl(const ge_strings *strings, const int32_t *src, const int32_t *src_vert, int32_t n_src,
+                                       const int32_t *tgt, const int32_t *tgt_vert, int32_t n_tgt,
+                                       const ge_sim_cfg *cfg, ge_sim_pairs **result) {
     if (!strings || !cfg || !result) return ge::fail(GE_ERR_ARG, "ge_similarity_pairs: null argument");
     *result = nullptr;
     if (n_src < 0 || n_tgt < 0 || strings->count < 0) return ge::fail(GE_ERR_ARG, "ge_similarity_pairs: negative count");
@@ -476,9 +477,10 @@ ge_status ge_similarity_pairs(const ge_strings *strings, const int32_t *src, con
     for (int32_t k = 0; k < n_tgt; ++k) if (tgt[k] < 0 || tgt[k] >= S) return ge::fail(GE_ERR_ARG, "target[%d] = %d outside the string table", k, tgt[k]);
     if (S && strings->offset[S] >= (int64_t)1 << 31) return ge::fail(GE_ERR_ARG, "string table larger than 2^31 code units");
 
-    auto out = new ge_sim_pairs();
-    if (n_src == 0 || n_tgt == 0) { *result = out; return GE_OK; }
-    if (ge_status st = ge::select_device(cfg->device)) { delete out; return st; }
+    std::unique_ptr<ge_sim_pairs> holder(new ge_sim_pairs());
+    ge_sim_pairs *out = holder.get();
+    if (n_src == 0 || n_tgt == 0) { *result = holder.release(); return GE_OK; }
+    if (ge_status st = ge::select_device(cfg->device)) return st;
 
     // ---- string table ------------------------------------------------------------------------------------
     const char16_t *U = reinterpret_cast<const char16_t *>(strings->units);
@@ -489,13 +491,12 @@ ge_status ge_similarity_pairs(const ge_strings *strings, const int32_t *src, con
     int max_len = 0;
     for (int32_t s = 0; s < S; ++s) {
         const int64_t b = strings->offset[s], e = strings->offset[s + 1];
-        if (e < b) { delete out; return ge::fail(GE_ERR_ARG, "string offsets must ascend"); }
+        if (e < b) { return ge::fail(GE_ERR_ARG, "string offsets must ascend"); }
         refs[(size_t)s] = {(int32_t)b, (int32_t)(e - b)};
         if (used[(size_t)s]) max_len = std::max<int>(max_len, (int)(e - b));
     }
     const bool string_kernel = cfg->method == GE_SIM_JAROWINKLER || cfg->method == GE_SIM_LEVENSHTEIN;
     if (max_len > MAX_UNITS) {
-        delete out;
         return ge::fail(GE_ERR_ARG, "a label of %d UTF-16 units exceeds the %d the similarity kernels take", max_len, MAX_UNITS);
     }
 
@@ -521,7 +522,7 @@ ge_status ge_similarity_pairs(const ge_strings *strings, const int32_t *src, con
                 a = b;
             }
             prof_norm[(size_t)s] = std::sqrt(sq);
-            if ((int)(gram_id.size() - (size_t)prof_ptr[(size_t)s]) > MAX_UNITS) { delete out; return ge::fail(GE_ERR_ARG, "profile with more than %d distinct grams", MAX_UNITS); }
+            if ((int)(gram_id.size() - (size_t)prof_ptr[(size_t)s]) > MAX_UNITS) { return ge::fail(GE_ERR_ARG, "profile with more than %d distinct grams", MAX_UNITS); }
         }
         prof_ptr[(size_t)S] = (int32_t)gram_id.size();
     }
@@ -562,7 +563,7 @@ ge_status ge_similarity_pairs(const ge_strings *strings, const int32_t *src, con
     DevBuf<uint16_t> d_units; DevBuf<StrRef> d_refs; DevBuf<int32_t> d_src, d_srcv, d_tgt, d_tgtv, d_pptr, d_gid, d_gcnt;
     DevBuf<double> d_norm; DevBuf<DateVal> d_date; DevBuf<uint8_t> d_dead; DevBuf<unsigned long long> d_counter;
     ge_status st = GE_OK;
-    auto fail = [&](ge_status s) { delete out; return s; };
+    auto fail = [&](ge_status s) { return s; };
     {
         const size_t total = (size_t)strings->offset[S];
         if ((st = d_units.alloc(total))) return fail(st);
@@ -649,7 +650,7 @@ ge_status ge_similarity_pairs(const ge_strings *strings, const int32_t *src, con
         }
         out->src.push_back(h.i); out->tgt.push_back(h.j); out->sim.push_back((float)sim);
     }
-    *result = out;
+    *result = holder.release();
     return GE_OK;
 }
 
@@ -663,5 +664,11 @@ ge_status ge_sim_pairs_get(const ge_sim_pairs *r, int64_t *count, const int32_t 
 }
 
 void ge_sim_pairs_destroy(ge_sim_pairs *r) { delete r; }
+
+ge_status ge_similarity_pairs(const ge_strings *strings, const int32_t *source, const int32_t *source_vertex, int32_t n_source,
+                              const int32_t *target, const int32_t *target_vertex, int32_t n_target,
+                              const ge_sim_cfg *cfg, ge_sim_pairs **result) {
+    GE_GUARD(similarity_pairs_impl(strings, source, source_vertex, n_source, target, target_vertex, n_target, cfg, result));
+}
 
 }  // extern "C"

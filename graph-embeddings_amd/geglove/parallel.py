@@ -40,6 +40,35 @@ class DeviceArray:
                                          "data": (int(ptr), False), "version": 2, "strides": None}
 
 
+class Bf16Context:
+    """Zero-copy torch views of a GE_DTYPE_BF16 handle's context rows (ge_glove_context_layout): the bf16 table and the
+    fp32 master rows of the columns that are hubs on this rank."""
+
+    def __init__(self, optimizer, device):
+        import ctypes as C
+        import torch
+        from . import capi
+        lay = capi.ContextLayout()
+        capi.check(capi.lib().ge_glove_context_layout(optimizer._h, C.byref(lay)))
+        if lay.dtype != capi.GE_DTYPE_BF16:
+            raise ValueError("the handle stores its context rows as fp32: pass them as `sums`")
+        self.vocab_size, self.dim, self.n_hub = lay.vocab_size, lay.dim, lay.n_hub
+        self.hub_index_ptr = lay.hub_index
+        self.table = torch.as_tensor(DeviceArray(lay.table, lay.vocab_size * lay.dim, "<i2"), device=device).view(torch.bfloat16)
+        self.hub_rows = (torch.as_tensor(DeviceArray(lay.hub_rows, lay.n_hub * lay.dim), device=device) if lay.n_hub
+                         else torch.empty(0, dtype=torch.float32, device=device))
+        self.hub_index = torch.as_tensor(DeviceArray(lay.hub_index, lay.vocab_size, "<i4"), device=device)
+
+    def values_f32(self):
+        """The current row values as one fp32 tensor [vocab_size * dim]: the bf16 table widened, hub rows from their masters."""
+        import torch
+        full = self.table.to(torch.float32).view(self.vocab_size, self.dim)
+        if self.n_hub:
+            cols = torch.nonzero(self.hub_index >= 0).view(-1)
+            full[cols] = self.hub_rows.view(self.n_hub, self.dim)[self.hub_index[cols].long()]
+        return full.view(-1).contiguous()
+
+
 class ContextSync:
     """Reconciles the replicated context-side tables after every rank has run its local pass.
 
@@ -56,7 +85,7 @@ class ContextSync:
     Works on CPU tensors with gloo (tests) and on device memory with nccl = RCCL over xGMI (bench.py).
     """
 
-    def __init__(self, sums, means, lazy_sums=(), lazy_every=4, wire="bf16", group=None):
+    def __init__(self, sums, means, lazy_sums=(), lazy_every=4, wire="bf16", group=None, bf16_tables=()):
         """lazy_sums: `sums` tables that are reconciled only every `lazy_every`-th call -- the AdaGrad accumulators:
         between syncs each rank keeps adding its own squared gradients (its steps are then at most sqrt(world)
         larger than with the global sum); the oracle simulation shows no difference in the cost trajectory
@@ -78,9 +107,18 @@ class ContextSync:
         self.old_m = [t.clone() for t in self.means]
         self.calls = 0
         self._wbuf = {}
+        # bf16_tables: Bf16Context objects -- context tables stored as bf16 with fp32 master rows for the hub columns
+        # (GE_DTYPE_BF16).  They only go through the take / land form below (ge_exchange_turn_bf16).
+        self.bf16 = list(bf16_tables)
+        if self.bf16 and self.world > 1:
+            self._entries()                             # their base is the row values NOW, before any local pass
 
     def sync(self):
         if self.world == 1:
+            return
+        if self.bf16:                                   # the bf16 layout has no torch-op form: take, all-reduce, land at once
+            self.begin()
+            self.finish()
             return
         torch, dist = self.torch, self.dist
         self.calls += 1
@@ -121,7 +159,8 @@ class ContextSync:
     # ---- overlapped exchange: the all-reduce of step k's deltas runs under step k+1 -------------------------
     #
     #   take   after the local pass of step k: delta_k = table - base is narrowed into the wire buffer, a copy of it
-    #          is kept ("own"), base = table, and the all-reduces start on the backend's own stream;
+    #          is kept ("own"), base += own (what bf16 dropped stays in table - base and leaves with the next delta), and
+    #          the all-reduces start on the backend's own stream;
     #   land   after the local pass of step k+1: waits for them and adds what the OTHER ranks contributed,
     #          merged_k - own_k, to the table (and to the base, so it is not taken for this rank's next delta).
     #
@@ -140,7 +179,14 @@ class ContextSync:
             self._ent = ([dict(t=t, o=o, mean=False, lazy=False, work=None) for t, o in zip(self.sums, self.old_s)] +
                          [dict(t=t, o=o, mean=False, lazy=True, work=None) for t, o in zip(self.lazy, self.old_l)] +
                          [dict(t=t, o=o, mean=True, lazy=False, work=None) for t, o in zip(self.means, self.old_m)])
+            for b in self.bf16:
+                t = b.table
+                e = dict(t=t, o=b.values_f32(), mean=False, lazy=False, work=None, bf16=b, fused=True, cnt=None,
+                         w=self.torch.empty_like(t), own=self.torch.empty_like(t))
+                self._ent.append(e)
             for e in self._ent:
+                if "bf16" in e:
+                    continue
                 t = e["t"]
                 narrow = self.wire == "bf16" and not e["mean"] and t.numel() >= (1 << 20)
                 e["w"] = self.torch.empty(t.shape, dtype=self.torch.bfloat16 if narrow else t.dtype, device=t.device)
@@ -152,6 +198,16 @@ class ContextSync:
     def _fused_turn(self, e, land, take):
         from . import capi                      # the HIP library; fails loudly when it has not been built
         t = e["t"]
+        if "bf16" in e:
+            b = e["bf16"]
+            self._seed = (getattr(self, "_seed", 0x5EED) * 1664525 + 1013904223) & 0xFFFFFFFF      # same on every call site, new per turn
+            with self.torch.cuda.device(t.device):
+                capi.check(capi.lib().ge_exchange_turn_bf16(
+                    t.data_ptr(), b.hub_rows.data_ptr() if b.n_hub else None, b.hub_index_ptr, b.vocab_size, b.dim,
+                    e["o"].data_ptr(), e["w"].data_ptr(), e["own"].data_ptr(), int(land), int(take),
+                    self._seed ^ (self.dist.get_rank(self.group) * 0x9E3779B1 & 0xFFFFFFFF),
+                    self.torch.cuda.current_stream(t.device).cuda_stream))
+            return
         with self.torch.cuda.device(t.device):
             capi.check(capi.lib().ge_exchange_turn(t.data_ptr(), e["o"].data_ptr(), e["w"].data_ptr(), e["own"].data_ptr(),
                                                    t.numel(), int(land), int(take),
@@ -189,7 +245,7 @@ class ContextSync:
                 if do_take:
                     torch.sub(t, o, out=w)
                     own.copy_(w)
-                    o.copy_(t)
+                    o.add_(own)                                         # the base advances by what is sent (error feedback)
             if do_take:
                 work = []
                 if e["mean"]:
@@ -216,5 +272,7 @@ class ContextSync:
         self.turn(everything=True)
         self.finish()
         for e in self._entries():
+            if "bf16" in e:
+                continue        # rows live partly in per-rank fp32 master rows (hub sets differ per rank): left as landed, equal up to bf16 rounding
             self.dist.broadcast(e["t"], src=src, group=self.group)
             e["o"].copy_(e["t"])

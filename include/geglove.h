@@ -286,13 +286,35 @@ void ge_sim_pairs_destroy(ge_sim_pairs *r);
  * replicated per GPU; after a local epoch each rank all-reduces the DELTA of its replica (RCCL, by the caller:
  * torch.distributed in geglove/parallel.py).  This entry point is the elementwise half, one pass over device
  * memory on `stream` (asynchronous):
- *   land != 0:  table += wire - own     `wire` holds the all-reduced sum of every rank's bf16 delta, `own` this
- *                                        rank's part of it, so the difference is what the others contributed;
- *   take != 0:  d = bf16(table - base) (before landing); wire = own = d; base = table (after landing).
- * With take == 0 the landed part is added to `base` too.  wire/own are bf16 (round to nearest even), 16-byte
- * aligned like table/base; count = elements. */
+ *   land != 0:  table += wire - own, base += wire - own     `wire` holds the all-reduced sum of every rank's bf16
+ *                                        delta, `own` this rank's part of it: the difference is what the others sent;
+ *   take != 0:  d = bf16(table - base) (before landing); wire = own = d; base += d.
+ * `base` starts as a copy of the table and is then always  consensus + this rank's deltas in flight  (consensus =
+ * start + every landed sum, identical on all ranks): what bf16 drops from a delta stays in table - base and leaves with
+ * the next one, so replicas differ by what is in flight plus one rounding however long the run.  wire/own are bf16
+ * (round to nearest even), 16-byte aligned like table/base; count = elements. */
 ge_status ge_exchange_turn(float *table, float *base, uint16_t *wire, uint16_t *own, int64_t count,
                            int32_t land, int32_t take, void *stream);
+
+/* Where the context rows of a handle live on the device (for the exchange above and below).  dtype GE_DTYPE_F32:
+ * `table` is float[vocab_size*dim] and the hub fields are NULL/0.  GE_DTYPE_BF16: `table` is bf16[vocab_size*dim];
+ * a column v with hub_index[v] >= 0 keeps its current value in hub_rows[hub_index[v]*dim ..] (fp32 master row; the
+ * bf16 copy of such a row is stale until extraction).  Which columns are hubs is decided per handle from ITS nonzeros. */
+typedef struct {
+    void          *table;
+    int32_t        dtype;        /* GE_DTYPE_* */
+    float         *hub_rows;     /* [n_hub x dim] */
+    const int32_t *hub_index;    /* [vocab_size], device memory */
+    int32_t        n_hub, vocab_size, dim;
+} ge_context_layout;
+ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out);
+
+/* ge_exchange_turn for a GE_DTYPE_BF16 context table: same land / take on the row values described by
+ * ge_context_layout.  `base` is float[vocab_size*dim] for EVERY row (start: the row values widened), wire / own are
+ * bf16[vocab_size*dim].  Landed ordinary rows are re-narrowed with stochastic rounding drawn from `seed` (a new one
+ * every turn); that rounding is part of table - base and is fed back with the next delta. */
+ge_status ge_exchange_turn_bf16(uint16_t *table, float *hub_rows, const int32_t *hub_index, int32_t vocab_size, int32_t dim,
+                                float *base, uint16_t *wire, uint16_t *own, int32_t land, int32_t take, uint32_t seed, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */
 const char *ge_last_error(void);     /* message of the calling thread's last failed call */

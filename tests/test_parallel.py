@@ -144,7 +144,7 @@ def _overlap_model(world, V, N, D, epochs, lazy_every=2):
         own = [{k: st[r][k] - base[r][k] for k in keys} for r in range(world)]
         for r in range(world):
             for k in keys:
-                base[r][k] = st[r][k].copy()
+                base[r][k] = base[r][k] + own[r][k]                    # the base advances by what is sent
         merged = {}
         for k in keys:
             total = own[0][k].copy()
