@@ -446,6 +446,8 @@ void ge_sim_cfg_default(ge_sim_cfg *cfg) {
     cfg->pattern = nullptr;               // getPattern: null -> "iso"
 }
 
+int32_t ge_sim_cfg_size(void) { return (int32_t)sizeof(ge_sim_cfg); }
+
 int32_t ge_sim_pattern_supported(const char *pattern) {
     DateFormat f;
     return DateFormat::compile(pattern, f) ? 1 : 0;
@@ -469,6 +471,11 @@ static ge_status similarity_pairs_impl(const ge_strings *strings, const int32_t 
     if (ngrams && ngram <= 0) return ge::fail(GE_ERR_ARG, "k should be positive!");                  // ShingleBased ctor
     const double smooth = cfg->smooth == 0 ? 1.0 : cfg->smooth;
     if (cfg->upper_triangle && n_src != n_tgt) return ge::fail(GE_ERR_ARG, "upper_triangle needs source == target");
+    int32_t job_begin = 0, job_end = n_src;
+    if (cfg->job_begin != 0 || cfg->job_end != 0) {
+        if (cfg->job_begin < 0 || cfg->job_end < cfg->job_begin || cfg->job_end > n_src) return ge::fail(GE_ERR_ARG, "job range [%d,%d) outside the %d jobs", cfg->job_begin, cfg->job_end, n_src);
+        job_begin = cfg->job_begin; job_end = cfg->job_end;
+    }
     DateFormat fmt;
     if (dates && !DateFormat::compile(cfg->pattern, fmt))
         return ge::fail(GE_ERR_ARG, "date pattern '%s' is outside the supported subset (iso, or yyyy/uuuu MM/M dd/d with literals)", cfg->pattern ? cfg->pattern : "");
@@ -479,7 +486,7 @@ static ge_status similarity_pairs_impl(const ge_strings *strings, const int32_t 
 
     std::unique_ptr<ge_sim_pairs> holder(new ge_sim_pairs());
     ge_sim_pairs *out = holder.get();
-    if (n_src == 0 || n_tgt == 0) { *result = holder.release(); return GE_OK; }
+    if (n_src == 0 || n_tgt == 0 || job_begin == job_end) { *result = holder.release(); return GE_OK; }
     if (ge_status st = ge::select_device(cfg->device)) return st;
 
     // ---- string table ------------------------------------------------------------------------------------
@@ -591,15 +598,15 @@ static ge_status similarity_pairs_impl(const ge_strings *strings, const int32_t 
 
     const int words = string_kernel ? (max_len + 31) / 32 : 1;
     const int64_t tiles = ((int64_t)n_tgt + SIM_BLOCK - 1) / SIM_BLOCK;
-    const int32_t rows_per_launch = (int32_t)std::max<int64_t>(1, std::min<int64_t>(n_src, ((int64_t)1 << 30) / tiles));
+    const int32_t rows_per_launch = (int32_t)std::max<int64_t>(1, std::min<int64_t>(job_end - job_begin, ((int64_t)1 << 30) / tiles));
     size_t cap = (size_t)1 << 22;                                        // pairs per launch before the buffers grow
     DevBuf<int32_t> d_oi, d_oj; DevBuf<double> d_os;
     if ((st = d_oi.alloc(cap)) || (st = d_oj.alloc(cap)) || (st = d_os.alloc(cap))) return fail(st);
     struct Hit { int32_t i, j; double sim; };
     std::vector<Hit> hits;
     std::vector<int32_t> hi, hj; std::vector<double> hs;
-    for (int32_t begin = 0; begin < n_src;) {
-        const int32_t count = std::min(rows_per_launch, n_src - begin);
+    for (int32_t begin = job_begin; begin < job_end;) {
+        const int32_t count = std::min(rows_per_launch, job_end - begin);
         p.src_begin = begin; p.src_count = count; p.out_i = d_oi.p; p.out_j = d_oj.p; p.out_sim = d_os.p; p.cap = cap;
         hipError_t e = hipMemset(d_counter.p, 0, sizeof(unsigned long long));
         if (e != hipSuccess) return fail(ge::fail(GE_ERR_HIP, "hipMemset: %s", hipGetErrorString(e)));

@@ -31,7 +31,7 @@ SYMBOLS = (
     "ge_glove_extract_f64", "ge_glove_get_state", "ge_glove_set_state", "ge_glove_device_ptr",
     "ge_glove_epoch_order", "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
     "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn", "ge_exchange_turn_bf16", "ge_glove_context_layout",
-    "ge_sim_cfg_default", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_device_count",
+    "ge_sim_cfg_default", "ge_sim_cfg_size", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_device_count",
 )
 
 
@@ -64,7 +64,7 @@ class BcaCfg(C.Structure):
 class SimCfg(C.Structure):
     _fields_ = [("method", C.c_int32), ("threshold", C.c_double), ("ngram", C.c_int32), ("smooth", C.c_double),
                 ("distance", C.c_double), ("time", C.c_int32), ("pattern", C.c_char_p), ("upper_triangle", C.c_int32),
-                ("device", C.c_int32)]
+                ("device", C.c_int32), ("job_begin", C.c_int32), ("job_end", C.c_int32)]
 
 
 class Strings(C.Structure):
@@ -144,6 +144,10 @@ def lib():
     L.ge_version.argtypes = []; L.ge_version.restype = C.c_char_p
     L.ge_device_count.argtypes = []; L.ge_device_count.restype = C.c_int32
     L.ge_glove_cfg_size.argtypes = []; L.ge_glove_cfg_size.restype = C.c_int32
+    L.ge_sim_cfg_size.argtypes = []; L.ge_sim_cfg_size.restype = C.c_int32
+    if L.ge_sim_cfg_size() != C.sizeof(SimCfg):
+        raise ImportError("libgeglove.so was built from another revision of include/geglove.h (ge_sim_cfg is %d bytes there, %d here): "
+                          "rebuild with `make -C graph-embeddings_amd/csrc`" % (L.ge_sim_cfg_size(), C.sizeof(SimCfg)))
     if L.ge_glove_cfg_size() != C.sizeof(GloveCfg):
         raise ImportError("libgeglove.so was built from another revision of include/geglove.h (ge_glove_cfg is %d bytes there, "
                           "%d here): rebuild with `make -C graph-embeddings_amd/csrc`" % (L.ge_glove_cfg_size(), C.sizeof(GloveCfg)))

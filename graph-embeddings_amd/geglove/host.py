@@ -427,8 +427,9 @@ class CompareGroup:
     def addToSource(self, vertex): self.source.append(int(vertex))
     def addToTarget(self, vertex): self.target.append(int(vertex))
 
-    def compare(self, vertex_labels):
-        """vertex_labels: vertex id -> label (g.getVertexLabelProperty())."""
+    def compare(self, vertex_labels, job_range=None):
+        """vertex_labels: vertex id -> label (g.getVertexLabelProperty()).  job_range = (begin, end): only those
+        CompareJobs (source positions) run -- the shard of one GPU; concatenating the shards gives the whole result."""
         g = self.group
         verts = sorted(set(self.source) | set(self.target))
         pos = {v: k for k, v in enumerate(verts)}
@@ -448,6 +449,8 @@ class CompareGroup:
         cfg.distance = g.distance; cfg.time = g.getTimeEnum()
         cfg.pattern = None if g.getPattern() == "iso" else g.getPattern().encode()
         cfg.upper_triangle = int(self.upperTriangle); cfg.device = self.device
+        if job_range is not None:
+            cfg.job_begin, cfg.job_end = int(job_range[0]), int(job_range[1])
         h = C.c_void_p()
         capi.check(L.ge_similarity_pairs(C.byref(table), _p(sp, C.c_int32), _p(sv, C.c_int32), len(sp),
                                          _p(tp, C.c_int32), _p(tv, C.c_int32), len(tp), C.byref(cfg), C.byref(h)))

@@ -439,6 +439,8 @@ struct CompareGroup {
     static CompareGroup from(const std::map<std::string, std::string> &m) {
         auto g = [&](const char *k, const char *def = "") { auto it = m.find(k); return it == m.end() ? std::string(def) : it->second; };
         CompareGroup c;
+        if (ge_sim_cfg_size() != (int32_t)sizeof(ge_sim_cfg))
+            throw std::runtime_error("libgeglove.so was built from another revision of include/geglove.h (ge_sim_cfg differs): rebuild host and library together");
         ge_sim_cfg_default(&c.cfg);
         c.sourcePredicate = g("sourcePredicate"); c.targetPredicate = g("targetPredicate");
         std::string method = g("method"), up = method;

@@ -252,6 +252,9 @@ typedef struct {
     int32_t upper_triangle;  /* CompareGroup.upperTriangle: source predicate == target predicate, job i starts
                                 at target i+1 (source and target must then be the same list)               */
     int32_t device;          /* HIP device ordinal                                                          */
+    int32_t job_begin;       /* multi-GPU sharding: only CompareJobs (source positions) [job_begin, job_end) run;    */
+    int32_t job_end;         /*   0,0 = all.  Positions in the result stay global; concatenating the shards' results
+                                in job order gives the whole group's result (no collective involved).             */
 } ge_sim_cfg;
 
 /* A table of java.lang.String values: string s = UTF-16 code units [offset[s], offset[s+1]) of `units`
@@ -265,6 +268,7 @@ typedef struct {
 typedef struct ge_sim_pairs ge_sim_pairs;
 
 void ge_sim_cfg_default(ge_sim_cfg *cfg);
+int32_t ge_sim_cfg_size(void);      /* sizeof(ge_sim_cfg) as the library was compiled (same purpose as ge_glove_cfg_size) */
 /* 1 when Date* can parse with this pattern (NULL/"iso" included), 0 when it is outside the supported subset. */
 int32_t ge_sim_pattern_supported(const char *pattern);
 /* source[i] / target[j] are positions in `strings` (vertexLabels.getValueAsString of sourceNodes[i] / targetNodes[j]),

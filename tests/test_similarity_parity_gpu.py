@@ -191,3 +191,30 @@ def test_many_pairs_grow_the_result_buffers(gpu):
     for q in k:
         v, _ = O.sim_pair(O.sim_cfg("jarowinkler"), labels[a[q]], labels[b[q]])
         assert np.float32(v) == sim[q]
+
+
+def test_job_ranges_shard_a_group(gpu):
+    """The multi-GPU form: each rank runs a block of CompareJobs; the blocks' results concatenated are the group's."""
+    from geglove import parallel
+    rng = np.random.default_rng(21)
+    labels = names(rng, 900)
+    lab = dict(enumerate(labels))
+
+    def group():
+        g = geglove.CompareGroup(geglove.SimilarityGroup(dict(method="jarowinkler", threshold=0.85, predicate="p")))
+        g.source = list(range(900)); g.target = list(range(900))
+        return g
+
+    whole = group(); whole.compare(lab)
+    parts = []
+    for rank in range(3):
+        g = group(); g.compare(lab, job_range=parallel.shard_rows(900, 3, rank)); parts.append(g.pairs)
+    assert all(len(p[0]) > 0 for p in parts)
+    for k in range(3):
+        np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), whole.pairs[k])
+    L = capi.lib()
+    cfg = capi.SimCfg(); L.ge_sim_cfg_default(C.byref(cfg)); cfg.job_begin, cfg.job_end = 5, 3
+    off = np.array([0, 3, 6], np.int64); units = np.zeros(6, np.uint16); idx = np.array([0, 1], np.int32)
+    table = capi.Strings(2, off.ctypes.data_as(C.POINTER(C.c_int64)), units.ctypes.data_as(C.POINTER(C.c_uint16)))
+    p = idx.ctypes.data_as(C.POINTER(C.c_int32)); h = C.c_void_p()
+    assert L.ge_similarity_pairs(C.byref(table), p, p, 2, p, p, 2, C.byref(cfg), C.byref(h)) == capi.GE_ERR_ARG
