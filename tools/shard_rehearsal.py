@@ -1,0 +1,52 @@
+"""What ONE rank of an N-GPU run does per step, measured on one GPU without communication: the epoch over its shard
+of the N-times larger problem (weak scaling: V = N x 625 000 vertices, this rank's 625 000 focus rows, the whole
+replicated context side) and the fused exchange passes over the replicated tables.
+    python tools/shard_rehearsal.py [ranks=8] [nnz_per_gpu=125000000] [dim=200]
+Everything but the all-reduce itself; with the all-reduce hidden under the next epoch this is the step time."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "graph-embeddings_amd"))
+import geglove                                   # noqa: E402
+from geglove import capi, parallel, synth        # noqa: E402
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+nnz = int(sys.argv[2]) if len(sys.argv) > 2 else 125_000_000
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+V = 625_000 * world
+rows = parallel.shard_rows(V, world, 0)
+I, J, X, xmax = synth.synthetic_coo_shard(V, rows, nnz, seed=0xC0FFEE)
+for reserve in (0, -256):
+    cfg = geglove.Configuration({"graph": "synthetic", "method": "glove", "dim": D, "threads": 1,
+                                 "bca": {"alpha": 0.1, "epsilon": 1e-3, "directed": True},
+                                 "opt": {"method": "adagrad", "tolerance": 0, "maxiter": 4}, "output": {"uri": []},
+                                 "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "workers": reserve,
+                                            "row_range": rows if world > 1 else (0, 0)}})
+    opt = geglove.createOptimizer(cfg, geglove.CooMatrix(V, I, J, X, xmax))
+    opt.epoch(0)
+    ms = []
+    for it in range(1, 4):
+        opt.epoch(it); ms.append(opt.last_kernel_ms()[0])
+    print("ranks %d: V = %d, %d nonzeros on this rank, dim %d, workers %d -> epoch %.2f ms (%.3g updates/s per GPU)"
+          % (world, V, len(I), D, opt.info()["groups_in_flight"], np.mean(ms), len(I) / np.mean(ms) * 1e3), flush=True)
+    if reserve == 0:
+        opt.close()
+dev = torch.device("cuda", 0)
+for name in ("context", "gsq_context"):
+    ptr, cnt = opt.device_ptr(name)
+    t = torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=dev)
+    base = t.clone(); w = torch.empty(cnt, dtype=torch.bfloat16, device=dev); own = torch.empty_like(w)
+    L = capi.lib()
+    L.ge_exchange_turn(t.data_ptr(), base.data_ptr(), w.data_ptr(), own.data_ptr(), cnt, 0, 1, None)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        L.ge_exchange_turn(t.data_ptr(), base.data_ptr(), w.data_ptr(), own.data_ptr(), cnt, 1, 1, None)
+    torch.cuda.synchronize()
+    print("fused exchange turn over %s (%d floats): %.2f ms; bf16 delta on the wire: %.2f GB" % (name, cnt, (time.perf_counter() - t0) / 3 * 1e3, cnt * 2 / 1e9), flush=True)
+    del base, w, own
