@@ -548,7 +548,16 @@ inline InMemoryGraph read_ntriples(const std::string &path, const Configuration 
     std::vector<CompareGroup> groups;
     std::unordered_map<std::string, size_t> sourceGroups, targetGroups;               // predicate -> group (:41-56; a later entry replaces an earlier one)
     if (similarity) {
-        for (auto &m : cfg.similarity) groups.push_back(CompareGroup::from(m));
+        for (auto &m : cfg.similarity) {
+            try { groups.push_back(CompareGroup::from(m)); }
+            catch (const std::runtime_error &e) {
+                // The shipped YAMLs are written in an older dialect (`predicate:` instead of source/targetPredicate, methods
+                // `token` / `jaccard`) that this revision's bean cannot load at all.  Such an entry is skipped with a
+                // warning, like the other legacy keys; in the current dialect an unknown method fails as valueOf does.
+                if (!m.count("predicate") || std::string(e.what()).find("SimilarityMethod") == std::string::npos) throw;
+                if (log) log(std::string("skipping legacy similarity entry for ") + m.at("predicate") + ": " + e.what());
+            }
+        }
         for (size_t k = 0; k < groups.size(); ++k) { sourceGroups[groups[k].sourcePredicate] = k; targetGroups[groups[k].targetPredicate] = k; }
     }
     auto addVertex = [&](const std::string &pred, const detail::Term &n) -> int32_t {     // Rdf2GrphConverter.addVertex

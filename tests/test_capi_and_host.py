@@ -140,3 +140,28 @@ def test_ntriples_ingest_follows_the_converter_rules(host):
     assert rows[6][3] == "out: 2(1.0) 4(1.0) 5(0.5) 8(1.0)"                 # parallel p2->p1 edges collapse, ascending ids
     assert rows[1][4] == "in: 0 4"
     assert keys[8] == "On machines@en" and keys[11] == "1843^^http://www.w3.org/2001/XMLSchema#gYear"
+
+
+def test_legacy_similarity_dialect_is_skipped_and_unknown_methods_fail(host, tmp_path):
+    """The shipped YAMLs use `predicate:` + methods `token` / `jaccard`, which this revision's SimilarityMethod enum
+    (Configuration.java:27-29) does not have: such entries are skipped; in the current dialect valueOf's failure is kept."""
+    host.geh_graph_summary_similarity.restype = C.c_char_p
+    base = ("graph: g.nt\nmethod: glove\ndim: 4\nbca:\n  alpha: 0.1\n  epsilon: 0.001\noutput:\n  uri: []\n"
+            "weights:\n  http://xmlns.com/foaf/0.1/name: 1\n  http://purl.org/dc/elements/1.1/title: 1\n  http://purl.org/dc/elements/1.1/creator: 1\n  http://purl.org/dc/terms/references: 1\n")
+    legacy = tmp_path / "legacy.yml"
+    legacy.write_text(base + "similarity:\n  - predicate: http://purl.org/dc/elements/1.1/title\n    method: token\n    threshold: 0.5\n"
+                             "  - predicate: http://xmlns.com/foaf/0.1/name\n    method: jaccard\n    ngram: 4\n    threshold: 0.75\n")
+    nt = os.path.join(GOLD, "tiny.nt").encode()
+    out = host.geh_graph_summary_similarity(str(legacy).encode(), nt).decode().splitlines()
+    assert out[0] == "OK" and out[1].endswith("pairs=0")                      # no group left, so no device call either
+    assert out[2:] == host.geh_graph_summary(str(legacy).encode(), nt).decode().splitlines()[2:]
+    modern = tmp_path / "modern.yml"
+    modern.write_text(base + "similarity:\n  - sourcePredicate: http://xmlns.com/foaf/0.1/name\n    targetPredicate: http://xmlns.com/foaf/0.1/name\n"
+                             "    method: token\n    threshold: 0.5\n")
+    out = host.geh_graph_summary_similarity(str(modern).encode(), nt).decode()
+    assert out.startswith("ERR") and "No enum constant" in out and "SimilarityMethod.TOKEN" in out
+    dates = tmp_path / "dates.yml"
+    dates.write_text(base + "similarity:\n  - sourcePredicate: http://xmlns.com/foaf/0.1/name\n    targetPredicate: http://xmlns.com/foaf/0.1/name\n"
+                            "    method: date_days\n    pattern: yyyy-MMM-dd\n    threshold: 0.5\n")
+    out = host.geh_graph_summary_similarity(str(dates).encode(), nt).decode()
+    assert out.startswith("ERR") and "pattern" in out
