@@ -166,7 +166,7 @@ class ContextSync:
     #
     # turn() = land what is in flight, then take; begin() = take only; finish() = land only.  The table itself is
     # never on the wire, so the local pass may keep updating it while the exchange is in flight; a rank sees the
-    # other ranks' moves one step late (tools/multirank_sim.py: the merged model trails the synchronous exchange
+    # other ranks' moves one step late (tests/tools/multirank_sim.py: the merged model trails the synchronous exchange
     # by about one epoch, stable).  Between turns the replicas differ by what is in flight and by the bf16
     # rounding of their own deltas; replicate() makes them identical again.
     #

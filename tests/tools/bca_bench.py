@@ -2,7 +2,7 @@
 """Times the device co-occurrence builder next to the CPU oracle on a synthetic DBLP-like graph and checks
 that the two outputs are identical.  Diagnostic (numbers quoted in DESIGN.md); not the headline bench."""
 import argparse, os, sys, time
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(REPO, "graph-embeddings_amd"), os.path.join(REPO, "oracle")]
 import numpy as np
 import geglove

@@ -2,7 +2,7 @@
 """Per-epoch mean cost of the device trainer (Hogwild) next to the sequential CPU oracle on the
 same matrix and seed.  Diagnostic for the statistical parity of the racy mode."""
 import argparse, os, sys, time
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(REPO, "graph-embeddings_amd"), os.path.join(REPO, "oracle")]
 import numpy as np
 import geglove

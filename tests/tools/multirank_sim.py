@@ -1,7 +1,7 @@
 """CPU simulation of the multi-GPU merge rules: W simulated ranks, each running the oracle's
 Adagrad.createJob restatement on its row shard against its own replica of the context side, merged once per epoch.
 
-  python tools/multirank_sim.py [--ranks 8] [--epochs 14] [--delay 0|1] ...
+  python tests/tools/multirank_sim.py [--ranks 8] [--epochs 14] [--delay 0|1] ...
 
 --delay 1 applies the other ranks' summed deltas one epoch late (the overlapped exchange of ContextSync.begin/finish:
 the all-reduce of epoch k's deltas runs under epoch k+1).  Prints mean cost per epoch divided by the single-process
@@ -13,7 +13,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "graph-embeddings_amd"))
 import oracle as O                      # noqa: E402

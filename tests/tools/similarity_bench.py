@@ -1,5 +1,5 @@
 """Literal-similarity throughput: ge_similarity_pairs on the GPU next to the oracle's CompareJob
-loop on one host core, on synthetic person names / titles.   python tools/similarity_bench.py [n] [--cpu-sample rows]
+loop on one host core, on synthetic person names / titles.   python tests/tools/similarity_bench.py [n] [--cpu-sample rows]
 
 Prints one JSON line per metric: comparisons/s on the device (whole call: upload, profiles, kernel, sort, download),
 comparisons/s of the CPU restatement on a sample of source rows, and that the two agree on the sample."""
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "graph-embeddings_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import geglove                      # noqa: E402
