@@ -536,8 +536,35 @@ inline InMemoryGraph read_ntriples(const std::string &path, const Configuration 
     std::ifstream f(path);
     if (!f) throw std::runtime_error("Cannot read graph file " + path);
     const std::string ext = path.size() > 3 ? path.substr(path.rfind('.') == std::string::npos ? 0 : path.rfind('.')) : "";
+    if (ext == ".tsv" || ext == ".edges") {
+        // Plain edge list: one directed edge per line, `source <tab> target [<tab> weight]`, '#' comments.
+        // Vertices get consecutive ids in order of first appearance (as Rdf2GrphConverter.addVertex does), all of type URI;
+        // there are no predicates, so `weights:` and `similarity:` do not apply.
+        InMemoryGraph g;
+        std::unordered_map<std::string, int32_t> ids;
+        std::vector<int32_t> src, dst; std::vector<float> wt;
+        auto vertex = [&](const std::string &name) { auto it = ids.find(name); if (it != ids.end()) return it->second; ids[name] = g.V; g.keys.push_back(name); g.types.push_back(URI); return g.V++; };
+        std::string line; long long lineno = 0;
+        while (std::getline(f, line)) {
+            ++lineno;
+            if (!line.empty() && line.back() == '\r') line.pop_back();
+            if (line.empty() || line[0] == '#') continue;
+            std::vector<std::string> col; size_t a = 0;
+            while (a <= line.size()) { const size_t b = line.find('\t', a); col.push_back(line.substr(a, b == std::string::npos ? std::string::npos : b - a)); if (b == std::string::npos) break; a = b + 1; }
+            if (col.size() < 2 || col.size() > 3 || col[0].empty() || col[1].empty())
+                throw std::runtime_error("graph file " + path + ":" + std::to_string(lineno) + ": expected `source<TAB>target[<TAB>weight]`");
+            float w = 1.0f;
+            if (col.size() == 3) { char *end = nullptr; w = std::strtof(col[2].c_str(), &end); if (end == col[2].c_str() || *end) throw std::runtime_error("graph file " + path + ":" + std::to_string(lineno) + ": weight is not a number"); }
+            ++g.triples;
+            const int32_t si = vertex(col[0]), oi = vertex(col[1]);
+            src.push_back(si); dst.push_back(oi); wt.push_back(w);
+        }
+        edges_to_csr(g.V, src, dst, wt, g.out_ptr, g.out_idx, g.out_w);
+        edges_to_csr(g.V, dst, src, wt, g.in_ptr, g.in_idx, g.in_w);
+        return g;
+    }
     if (ext != ".nt" && ext != ".ntriples")
-        throw std::runtime_error("graph file " + path + ": only N-Triples (.nt) is read natively (the reference parses ttl/trig/hdt through Jena, which is out of scope); convert the file first");
+        throw std::runtime_error("graph file " + path + ": only N-Triples (.nt) and tab-separated edge lists (.tsv, .edges) are read natively (the reference parses ttl/trig/hdt through Jena, which is out of scope); convert the file first");
     InMemoryGraph g;
     std::unordered_map<std::string, int32_t> vertexMap;                                      // non-literals
     std::unordered_map<std::string, std::unordered_map<std::string, int32_t>> predLit;       // literals merged PER PREDICATE (:202-213)

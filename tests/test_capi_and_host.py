@@ -165,3 +165,22 @@ def test_legacy_similarity_dialect_is_skipped_and_unknown_methods_fail(host, tmp
                             "    method: date_days\n    pattern: yyyy-MMM-dd\n    threshold: 0.5\n")
     out = host.geh_graph_summary_similarity(str(dates).encode(), nt).decode()
     assert out.startswith("ERR") and "pattern" in out
+
+
+def test_edge_list_reader(host, tmp_path):
+    """`source<TAB>target[<TAB>weight]`: ids by first appearance, parallel edges collapse (first wins)."""
+    g = tmp_path / "g.tsv"
+    g.write_text("# a comment\nn1\tn2\nn2\tn3\t0.5\nn1\tn2\t9\nn3\tn1\t2\r\n")
+    cfg = tmp_path / "c.yml"
+    cfg.write_text("graph: %s\nmethod: glove\ndim: 4\nbca:\n  alpha: 0.1\n  epsilon: 0.001\noutput:\n  uri: []\n" % g)
+    out = host.geh_graph_summary(str(cfg).encode(), str(g).encode()).decode().splitlines()
+    assert out[0] == "OK" and out[1] == "V=3 triples=4 skipped=0"
+    rows = [l.split("\t") for l in out[2:]]
+    assert [r[2] for r in rows] == ["n1", "n2", "n3"] and all(r[1] == "0" for r in rows)
+    assert rows[0][3] == "out: 1(1.0)" and rows[1][3] == "out: 2(0.5)" and rows[2][3] == "out: 0(2.0)"
+    assert rows[0][4] == "in: 2" and rows[1][4] == "in: 0"
+    bad = tmp_path / "bad.tsv"; bad.write_text("n1\tn2\tx\n")
+    assert host.geh_graph_summary(str(cfg).encode(), str(bad).encode()).decode().startswith("ERR")
+    other = tmp_path / "g.ttl"; other.write_text("")
+    err = host.geh_graph_summary(str(cfg).encode(), str(other).encode()).decode()
+    assert err.startswith("ERR") and "N-Triples" in err and ".tsv" in err
