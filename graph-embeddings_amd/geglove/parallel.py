@@ -89,10 +89,12 @@ class ContextSync:
         """lazy_sums: `sums` tables that are reconciled only every `lazy_every`-th call -- the AdaGrad accumulators:
         between syncs each rank keeps adding its own squared gradients (its steps are then at most sqrt(world)
         larger than with the global sum); the oracle simulation shows no difference in the cost trajectory
-        (within 1 %) between syncing them every step, every 4th step or never, and it halves the bytes."""
-        """wire: "bf16" sends the deltas of the large tables as bf16 (half the bytes over xGMI); they are small
+        (within 1 %) between syncing them every step, every 4th step or never, and it halves the bytes.
+        wire: "bf16" sends the deltas of the large tables as bf16 (half the bytes over xGMI); they are small
         increments on top of an fp32 table that never leaves the GPU, and the oracle simulation shows cost
-        trajectories identical to three decimals with a bf16 ring sum.  "f32" sends them as they are."""
+        trajectories identical to three decimals with a bf16 ring sum.  "f32" sends them as they are.
+        bf16_tables: Bf16Context objects (context rows stored as bf16 + fp32 hub master rows, GE_DTYPE_BF16); they take
+        the begin / finish / turn form only (sync() then is begin() + finish())."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
