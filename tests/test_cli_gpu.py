@@ -17,11 +17,11 @@ EXE = os.path.join(REPO, "graph-embeddings_amd", "bin", "geglove")
 GOLD = os.path.join(REPO, "tests", "golden")
 
 
-def _graph_from_host():
+def _graph_from_host(config="tiny.config.yml", nt="tiny.nt", similarity=False):
     L = C.CDLL(os.path.join(REPO, "graph-embeddings_amd", "lib", "libgehost.so"))
-    L.geh_graph_summary.restype = C.c_char_p
-    out = L.geh_graph_summary(os.path.join(REPO, "tests/golden/tiny.config.yml").encode(),
-                              os.path.join(REPO, "tests/golden/tiny.nt").encode()).decode().splitlines()
+    fn = L.geh_graph_summary_similarity if similarity else L.geh_graph_summary
+    fn.restype = C.c_char_p
+    out = fn(os.path.join(REPO, "tests/golden", config).encode(), os.path.join(REPO, "tests/golden", nt).encode()).decode().splitlines()
     V = int(re.match(r"V=(\d+)", out[1]).group(1))
     src, dst, w, keys, types = [], [], [], [], []
     for line in out[2:]:
@@ -171,3 +171,35 @@ def test_host_ingest_adds_the_similarity_edges(gpu):
     # spot checks a reader can follow: the two spellings of the same name are linked, equal names on two predicates are not merged
     a, b = ids["Jan Jansen"], ids["Jan Janssen"]
     assert b in full[a][1] and a in full[b][1] and full[a][1][b] == full[b][1][a]
+
+
+def test_cli_end_to_end_with_similarity_edges(gpu, tmp_path):
+    """similar.config.yml through the CLI: ingest, four similarity groups on the device, builder, trainer (deterministic mode),
+    writer.  The vectors equal the oracle pipeline run on the graph the ingest test above checks edge by edge."""
+    cwd = tmp_path
+    os.makedirs(cwd / "tests" / "golden")
+    for f in ("similar.config.yml", "similar.nt"):
+        (cwd / "tests" / "golden" / f).write_bytes(open(os.path.join(GOLD, f), "rb").read())
+    r = subprocess.run([EXE, "-c", "tests/golden/similar.config.yml"], cwd=cwd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "Processing similarities for predicate http://xmlns.com/foaf/0.1/name" in r.stdout
+    made = [int(m) for m in re.findall(r"Created links for (\d+) literal pairs", r.stdout)]
+    assert len(made) == 4 and sum(made) >= 6
+    name = "similar_glove_partial_directed_0.1_0.001_adagrad_8"
+    vec = (cwd / "out" / (name + ".vectors.tsv")).read_text().splitlines()
+    dic = (cwd / "out" / (name + ".dict.tsv")).read_text().splitlines()
+    k = dic.index("key\ttype")
+    rows, body_v = dic[k + 1:], vec[k:]
+    assert [r_.split("\t")[0] for r_ in rows] == ["http://ex.org/a/%d" % a for a in range(1, 10)]
+    g, keys, types = _graph_from_host("similar.config.yml", "similar.nt", similarity=True)
+    coo = O.bca_build(g["V"], g["out"], g["inn"], 0.1, 1e-3, True, O.NORM_NONE)
+    m = O.Glove(g["V"], 8, coo["I"], coo["J"], coo["X"], coo["max"], O.COST_GLOVE, seed=42, threads=1)
+    m.optimize(3, 1e-4)
+    ref = m.extract()
+    want = [i for i, key in enumerate(keys) if key.startswith("http://ex.org/a/")]
+    for l, i in zip(body_v, want):
+        assert l.split("\t") == [O.format_11_6E(v) for v in ref[i]]          # byte-identical text
+    # the similarity edges matter: without them the numbers differ
+    g0, _, _ = _graph_from_host("similar.config.yml", "similar.nt", similarity=False)
+    coo0 = O.bca_build(g0["V"], g0["out"], g0["inn"], 0.1, 1e-3, True, O.NORM_NONE)
+    assert len(coo0["I"]) < len(coo["I"])
