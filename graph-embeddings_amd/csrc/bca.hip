@@ -27,6 +27,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <memory>
 #include <new>
 #include <vector>
 
@@ -453,11 +455,23 @@ __global__ void k_gather_rows(const int32_t *poolJ, const float *poolX, const in
 
 }  // namespace
 
+// GE_BCA_TIMING=1 prints the phases of ge_bca_build to stderr
+struct PhaseClock {
+    bool on = std::getenv("GE_BCA_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[ge_bca_build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 struct ge_coo {
     int64_t nnz = 0;
     int32_t V = 0;
-    std::vector<int32_t> I, J;
-    std::vector<float> X;
+    std::unique_ptr<int32_t[]> I, J;      // nnz entries each; left uninitialised until the device copy fills them
+    std::unique_ptr<float[]> X;           //   (a value-initialising container would touch 12 bytes per entry once more)
     std::vector<int64_t> row_ptr;
     double max = 0;
 };
@@ -501,6 +515,7 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     int32_t rb = cfg->row_begin, re = cfg->row_end;
     if (rb == 0 && re == 0) re = V;
     if (rb < 0 || re > V || rb >= re) return ge::fail(GE_ERR_ARG, "invalid bookmark range [%d,%d)", rb, re);
+    PhaseClock clk;
     const int64_t Eo = out_nbrs->ptr[V], Ei = in_nbrs->ptr[V];
     if (out_nbrs->ptr[0] != 0 || in_nbrs->ptr[0] != 0 || Eo < 0 || Ei < 0) return ge::fail(GE_ERR_ARG, "CSR offsets must start at 0");
     for (int32_t v = 0; v < V; ++v)
@@ -647,6 +662,7 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
         break;
     }
     dev.keep(d_work); dev.keep(d_pJ); dev.keep(d_pX);
+    clk.lap("upload + k_bca passes");
 
     ge_coo *c = new (std::nothrow) ge_coo();
     if (!c) return ge::fail(GE_ERR_OOM, "host allocation failed");
@@ -668,7 +684,9 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     double mx = 0;
     for (int32_t r = 0; r < n_rows; ++r) mx = java_math_max(mx, (double)h_max[(size_t)r]);
     c->max = mx;
-    c->I.resize((size_t)total); c->J.resize((size_t)total); c->X.resize((size_t)total);
+    clk.lap("row sizes, offsets, max");
+    c->I.reset(new int32_t[(size_t)std::max<int64_t>(total, 1)]); c->J.reset(new int32_t[(size_t)std::max<int64_t>(total, 1)]); c->X.reset(new float[(size_t)std::max<int64_t>(total, 1)]);
+    clk.lap("host result arrays");
     if (total > 0) {
         int64_t *d_dst = nullptr; int32_t *d_I = nullptr, *d_J = nullptr; float *d_X = nullptr;
         bool good = hipMalloc((void **)&d_dst, sizeof(int64_t) * (size_t)n_rows) == hipSuccess; if (good) dev.keep(d_dst);
@@ -682,10 +700,13 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
                                d_pJ, d_pX, d_pJ2, d_pX2, pool_cap, d_row_off, d_row_n, d_dst, n_rows, rb, d_I, d_J, d_X);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipMemcpy(c->I.data(), d_I, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(c->J.data(), d_J, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(c->X.data(), d_X, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        clk.lap("k_gather_rows");
+        if (e == hipSuccess) e = hipMemcpy(c->I.get(), d_I, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(c->J.get(), d_J, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(c->X.get(), d_X, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { delete c; return ge::fail(GE_ERR_HIP, "COO gather failed: %s", hipGetErrorString(e)); }
+        clk.lap("copy out");
     }
     *result = c;
     return GE_OK;
@@ -695,9 +716,9 @@ ge_status ge_coo_get(const ge_coo *c, int64_t *nnz, const int32_t **I, const int
                      const int64_t **row_ptr, double *max) {
     if (!c) return ge::fail(GE_ERR_ARG, "null ge_coo handle");
     if (nnz) *nnz = c->nnz;
-    if (I) *I = c->I.data();
-    if (J) *J = c->J.data();
-    if (X) *X = c->X.data();
+    if (I) *I = c->I.get();
+    if (J) *J = c->J.get();
+    if (X) *X = c->X.get();
     if (row_ptr) *row_ptr = c->row_ptr.data();
     if (max) *max = c->max;
     return GE_OK;
