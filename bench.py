@@ -127,9 +127,13 @@ def main():
         "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot, "dtype": args.dtype,
                    "workers": -args.reserve_waves if (world > 1 and args.exchange == "overlap") else 0,
                    "row_range": rows if world > 1 else (0, 0)}})
+    t_create = time.perf_counter()
     opt = geglove.createOptimizer(cfg, geglove.CooMatrix(V, I, J, X, xmax))
+    t_create = time.perf_counter() - t_create
 
     sync = None
+    if world > 1 and args.opt != "adagrad":
+        raise SystemExit("bench.py --gpus N: the context exchange (which deltas add, which average) is defined for adagrad only")
     if world > 1:
         dev = torch.device("cuda", local_rank)
 
@@ -228,7 +232,7 @@ def main():
                          "kernel_updates_per_s": n_local / avg_kernel_s},
             "mean_cost_first_last": [costs[0] / n_local, costs[-1] / n_local],
             "trainer": opt.info(),
-            "gen_seconds": t_gen,
+            "gen_seconds": t_gen, "create_seconds": t_create,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, V, D, I, J, X, xmax)
