@@ -46,6 +46,7 @@ def parse():
                          "'sync' exchanges after every step before the next one starts")
     ap.add_argument("--reserve-waves", type=int, default=256,
                     help="N>1 with --exchange overlap: wavefront slots the epoch kernel leaves free for the all-reduce kernels")
+    ap.add_argument("--workers", type=int, default=0, help="sequential workers (wavefronts); 0 = fill the device (cfg.workers)")
     ap.add_argument("--accum-sync-every", type=int, default=4, help="every how many context syncs the AdaGrad accumulators are reconciled too (N>1)")
     return ap.parse_args()
 
@@ -125,7 +126,7 @@ def main():
         "opt": {"method": args.opt, "tolerance": 0, "maxiter": args.steps},
         "output": {"uri": []},
         "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot, "dtype": args.dtype,
-                   "workers": -args.reserve_waves if (world > 1 and args.exchange == "overlap") else 0,
+                   "workers": args.workers if args.workers else (-args.reserve_waves if (world > 1 and args.exchange == "overlap") else 0),
                    "row_range": rows if world > 1 else (0, 0)}})
     t_create = time.perf_counter()
     opt = geglove.createOptimizer(cfg, geglove.CooMatrix(V, I, J, X, xmax))
@@ -135,20 +136,7 @@ def main():
     if world > 1 and args.opt != "adagrad":
         raise SystemExit("bench.py --gpus N: the context exchange (which deltas add, which average) is defined for adagrad only")
     if world > 1:
-        dev = torch.device("cuda", local_rank)
-
-        def wrap(name):
-            ptr, cnt = opt.device_ptr(name)
-            return torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=dev)
-
-        if args.dtype == "bf16":       # context rows: bf16 table + fp32 master rows of this rank's hub columns
-            sync = parallel.ContextSync(sums=[], means=[wrap("cbias")], bf16_tables=[parallel.Bf16Context(opt, dev)],
-                                        lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=args.accum_sync_every,
-                                        wire=args.wire)
-        else:
-            sync = parallel.ContextSync(sums=[wrap("context")], means=[wrap("cbias")],
-                                        lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=args.accum_sync_every,
-                                        wire=args.wire)
+        sync = parallel.context_sync_for(opt, torch.device("cuda", local_rank), lazy_every=args.accum_sync_every, wire=args.wire)
 
     def step(it):
         c = opt.epoch(it)

@@ -76,6 +76,47 @@ __global__ __launch_bounds__(256) void k_exchange_turn(float *__restrict__ table
     }
 }
 
+// The same turn over the ROW part of a table of fat rows (fp32 Hogwild layout: row_stride = dim + 4 floats, the row's
+// bias at [dim], padding behind it): columns >= cols are left alone (the bias follows another merge rule, the padding
+// stays zero) and their wire / own slots are written as zero on a take so the all-reduce can run over the whole buffer.
+template <bool LAND, bool TAKE, int G>      // G = elements per lane: 4 (row_stride and cols multiples of 4) or 1
+__global__ __launch_bounds__(256) void k_exchange_turn_rows(float *__restrict__ table, float *__restrict__ base,
+                                                            uint16_t *__restrict__ wire, uint16_t *__restrict__ own,
+                                                            int64_t n_groups, int32_t stride_g, int32_t cols_g) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += step) {
+        const int32_t c = (int32_t)(g % stride_g);
+        if (c >= cols_g) {
+            if (TAKE) {
+                if (G == 4) { reinterpret_cast<uint2 *>(wire)[g] = make_uint2(0, 0); reinterpret_cast<uint2 *>(own)[g] = make_uint2(0, 0); }
+                else { wire[g] = 0; own[g] = 0; }
+            }
+            continue;
+        }
+        if (G == 4) {
+            float4 tv = reinterpret_cast<const float4 *>(table)[g], bv = reinterpret_cast<const float4 *>(base)[g];
+            uint2 wv = LAND ? reinterpret_cast<const uint2 *>(wire)[g] : make_uint2(0, 0), ov = LAND ? reinterpret_cast<const uint2 *>(own)[g] : make_uint2(0, 0);
+            float t[4] = {tv.x, tv.y, tv.z, tv.w}, b[4] = {bv.x, bv.y, bv.z, bv.w};
+            uint32_t w[4] = {wv.x & 0xffffu, wv.x >> 16, wv.y & 0xffffu, wv.y >> 16}, o[4] = {ov.x & 0xffffu, ov.x >> 16, ov.y & 0xffffu, ov.y >> 16};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) turn_one<LAND, TAKE>(t[k], b[k], w[k], o[k]);
+            if (LAND) reinterpret_cast<float4 *>(table)[g] = make_float4(t[0], t[1], t[2], t[3]);
+            reinterpret_cast<float4 *>(base)[g] = make_float4(b[0], b[1], b[2], b[3]);
+            if (TAKE) {
+                reinterpret_cast<uint2 *>(wire)[g] = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
+                reinterpret_cast<uint2 *>(own)[g]  = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+            }
+        } else {
+            float t = table[g], b = base[g];
+            uint32_t w = LAND ? wire[g] : 0u, o = LAND ? own[g] : 0u;
+            turn_one<LAND, TAKE>(t, b, w, o);
+            if (LAND) table[g] = t;
+            base[g] = b;
+            if (TAKE) { wire[g] = (uint16_t)w; own[g] = (uint16_t)o; }
+        }
+    }
+}
+
 // The same turn for a context table stored as bf16 with fp32 master rows for the hub columns (GE_DTYPE_BF16,
 // BASELINE config C5).  A row's value lives in hub_rows[hub_index[v]] (fp32) when the column is a hub ON THIS RANK
 // (hub sets differ per rank: each sees its own shard), else in the bf16 table; the wire carries every row either way.
@@ -160,6 +201,34 @@ extern "C" ge_status ge_exchange_turn_bf16(uint16_t *table, float *hub_rows, con
     if (land && take)  hipLaunchKernelGGL((k_exchange_turn_bf16<true, true>),  dim3(blocks), dim3(256), 0, s, table, hub_rows, hub_index, dim / 4, n4, base, wire, own, seed);
     else if (land)     hipLaunchKernelGGL((k_exchange_turn_bf16<true, false>), dim3(blocks), dim3(256), 0, s, table, hub_rows, hub_index, dim / 4, n4, base, wire, own, seed);
     else               hipLaunchKernelGGL((k_exchange_turn_bf16<false, true>), dim3(blocks), dim3(256), 0, s, table, hub_rows, hub_index, dim / 4, n4, base, wire, own, seed);
+    GE_HIP(hipGetLastError());
+    return GE_OK;
+}
+
+extern "C" ge_status ge_exchange_turn_rows(float *table, float *base, uint16_t *wire, uint16_t *own, int64_t rows, int32_t row_stride,
+                                           int32_t cols, int32_t land, int32_t take, void *stream) {
+    if (!table || !base || !wire || !own) return ge::fail(GE_ERR_ARG, "ge_exchange_turn_rows: null pointer");
+    if (rows < 0 || row_stride <= 0 || cols < 0 || cols > row_stride) return ge::fail(GE_ERR_ARG, "ge_exchange_turn_rows: need 0 <= cols <= row_stride, rows >= 0");
+    if (((uintptr_t)table | (uintptr_t)base) % 16 || ((uintptr_t)wire | (uintptr_t)own) % 8)
+        return ge::fail(GE_ERR_ARG, "ge_exchange_turn_rows: misaligned buffer");
+    if ((!land && !take) || rows == 0) return GE_OK;
+    int dev = 0, cus = 256;
+    GE_HIP(hipGetDevice(&dev));
+    GE_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const bool by4 = row_stride % 4 == 0 && cols % 4 == 0;
+    const int64_t n_groups = rows * (int64_t)(by4 ? row_stride / 4 : row_stride);
+    const int32_t sg = by4 ? row_stride / 4 : row_stride, cg = by4 ? cols / 4 : cols;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_groups + 255) / 256, (int64_t)cus * 8));
+    hipStream_t s = (hipStream_t)stream;
+#define GE_LAUNCH_ROWS(L, T)                                                                                                              \
+    do {                                                                                                                                  \
+        if (by4) hipLaunchKernelGGL((k_exchange_turn_rows<L, T, 4>), dim3(blocks), dim3(256), 0, s, table, base, wire, own, n_groups, sg, cg); \
+        else     hipLaunchKernelGGL((k_exchange_turn_rows<L, T, 1>), dim3(blocks), dim3(256), 0, s, table, base, wire, own, n_groups, sg, cg); \
+    } while (0)
+    if (land && take) GE_LAUNCH_ROWS(true, true);
+    else if (land)    GE_LAUNCH_ROWS(true, false);
+    else              GE_LAUNCH_ROWS(false, true);
+#undef GE_LAUNCH_ROWS
     GE_HIP(hipGetLastError());
     return GE_OK;
 }

@@ -52,6 +52,7 @@ struct GloveParams {
     double xmax;
     int64_t N;
     int32_t D;
+    int32_t DS;            // row stride of the fp32 tables in floats: D, or D + 4 when a row carries its bias at [D] (Hogwild)
     int32_t cost_kind;
     float lr;
     int32_t order_mode;
@@ -145,6 +146,23 @@ __global__ void k_extract(const float *focus, const float *context, OUT *out, in
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) out[i] = (OUT)((focus[i] + context[i]) / 2.0f);
+}
+
+// Fat rows (fp32 Hogwild tables): [row(D) | bias | 3 x 0].  Columns [col0, col0+ncols) of `rows` fat rows <-> a dense
+// [rows x ncols] array: ncols = D, col0 = 0 is the row table as the API shows it, ncols = 1, col0 = D its bias vector.
+__global__ void k_fat_gather(const float *fat, int64_t rows, int32_t DS, int32_t col0, int32_t ncols, float *dense) {
+    const int64_t n = rows * ncols, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / ncols; const int32_t c = (int32_t)(i - r * ncols);
+        dense[i] = fat[r * DS + col0 + c];
+    }
+}
+__global__ void k_fat_scatter(float *fat, int64_t rows, int32_t DS, int32_t col0, int32_t ncols, const float *dense) {
+    const int64_t n = rows * ncols, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / ncols; const int32_t c = (int32_t)(i - r * ncols);
+        fat[r * DS + col0 + c] = dense[i];
+    }
 }
 
 // bf16 embeddings (BASELINE config C5): storage conversions.  Round-to-nearest-even on the way in (init, set_state).
@@ -348,11 +366,15 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
     using VT = typename Vec<VW>::T;
     static_assert(!EMB16 || VW == 4, "bf16 embeddings need dim % 4 == 0");
     constexpr bool MOM = OPT != GE_OPT_ADAGRAD;
+    // FAT rows (every fp32 Hogwild table): a row is D + 4 floats, element [D] is the row's bias (in the accumulator /
+    // moment tables: the bias accumulator / moment), the rest padding that stays zero.  The bias rides in the sector
+    // the row's tail already occupies, so a streamed update costs four row accesses and no 4-byte ones.
+    constexpr bool FAT = !EMB16;
     uint32_t sr_state = 0x9E3779B9u * (uint32_t)(threadIdx.x + 1) + (uint32_t)blockIdx.x * 0x85EBCA6Bu + p.bij_key[0];
     // embedding-row access: fp32 build = plain 16-byte vectors; bf16 build = 8 bytes widened / narrowed here
     auto emb_rsrc = [&](float *base, int64_t id) {
         if constexpr (EMB16) return make_rsrc(reinterpret_cast<uint16_t *>(base) + id * p.D, (uint32_t)p.D * 2u);
-        else return make_rsrc(base + id * p.D, (uint32_t)p.D * 4u);
+        else return make_rsrc(base + id * p.DS, (uint32_t)p.DS * 4u);
     };
     auto emb_load = [&](__amdgpu_buffer_rsrc_t rs, int q) -> VT {
         if constexpr (EMB16) {
@@ -387,7 +409,9 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
     };
     const int lane = threadIdx.x & 63;
     const int32_t D = p.D;
-    const uint32_t row_bytes = (uint32_t)D * 4u;
+    const int32_t DS = p.DS;
+    const uint32_t row_bytes = (uint32_t)DS * 4u;
+    const int bl_q = (D / VW) >> 6, bl_lane = (D / VW) & 63;     // FAT: the lane and register chunk that hold element [D]
     const float lr = p.lr;
     const int wave = rfl((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (wave >= n_workers) return;          // workers pull chunks of the epoch order from one queue
@@ -488,6 +512,14 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             // and re-read every flush_every nonzeros, so workers on one hub stay within that many updates of
             // each other.
             if (!cur_hot || MOM) {
+                if constexpr (FAT) {                       // the bias goes out with its row
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q)
+                        if (q == bl_q && lane == bl_lane) {
+                            comp<VW>(a[q], 0) = ab; comp<VW>(ga[q], 0) = gab;
+                            if constexpr (MOM) comp<VW>(ha[q], 0) = hab;
+                        }
+                }
 #pragma unroll
                 for (int q = 0; q < NCH; ++q) {
                     if (EMB16 && !cur_a32) emb_store(a[q], rs_a, q);
@@ -531,7 +563,12 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             // The bias takes AdaGrad steps WITHOUT a learning rate (Adagrad.java:88-89): one run alone
             // already moves it most of the way, so concurrent hub runs must not add up.  The scalars are
             // merged last-writer-wins (what the Java race does), written through (sc1) like every table.
-            if (lane == 0) {
+            if constexpr (FAT) {
+                if (lane == 0 && cur_hot && !MOM) {        // rows went out as atomic deltas: the bias slot of each row is stored on its own
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ab), rs_a, D * 4, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gab), rs_ga, D * 4, 0, AUX_SC1);
+                }
+            } else if (lane == 0) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ab), make_rsrc(A_bias + cur_id, 4), 0, 0, AUX_SC1);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gab), make_rsrc(A_gsb + cur_id, 4), 0, 0, AUX_SC1);
                 if constexpr (MOM) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hab), make_rsrc(A_m2b + cur_id, 4), 0, 0, AUX_SC1);
@@ -557,17 +594,19 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
         };
         auto request_streamed = [&]() {
             const __amdgpu_buffer_rsrc_t rb = emb_rsrc(B_rows, n_oth);
-            const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)n_oth * D, row_bytes);
-            const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)n_oth * D, MOM ? row_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)n_oth * DS, row_bytes);
+            const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)n_oth * DS, MOM ? row_bytes : 0u);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
                 nb[q]  = emb_load(rb, q);
                 ngb[q] = buf_load<VW, AUX_SC1>(rg, (lane + q * 64) * VW * 4);
                 if constexpr (MOM) nhb[q] = buf_load<VW, AUX_SC1>(rh, (lane + q * 64) * VW * 4);
             }
-            n_bb  = buf_load_f32(make_rsrc(B_bias + n_oth, 4), 0, true);
-            n_gbb = buf_load_f32(make_rsrc(B_gsb + n_oth, 4), 0, true);
-            if constexpr (MOM) n_hbb = buf_load_f32(make_rsrc(B_m2b + n_oth, 4), 0, true);
+            if constexpr (!FAT) {
+                n_bb  = buf_load_f32(make_rsrc(B_bias + n_oth, 4), 0, true);
+                n_gbb = buf_load_f32(make_rsrc(B_gsb + n_oth, 4), 0, true);
+                if constexpr (MOM) n_hbb = buf_load_f32(make_rsrc(B_m2b + n_oth, 4), 0, true);
+            }
         };
         auto request_resident = [&]() {
             const int32_t id = n_key < 0 ? ~n_key : n_key;
@@ -575,9 +614,9 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
                 n_a32 = res_is_ctx && p.hot_enabled != 0;                  // hub chunk: fp32 master row
                 if (n_a32) rsN_a = make_rsrc(p.hub32 + (int64_t)p.hub_index[id] * D, row_bytes);
                 else rsN_a = emb_rsrc(A_rows, id);
-            } else rsN_a = make_rsrc(A_rows + (int64_t)id * D, row_bytes);
-            rsN_ga = make_rsrc(A_gs + (int64_t)id * D, row_bytes);
-            rsN_ha = make_rsrc(A_m2 + (int64_t)id * D, MOM ? row_bytes : 0u);
+            } else rsN_a = make_rsrc(A_rows + (int64_t)id * DS, row_bytes);
+            rsN_ga = make_rsrc(A_gs + (int64_t)id * DS, row_bytes);
+            rsN_ha = make_rsrc(A_m2 + (int64_t)id * DS, MOM ? row_bytes : 0u);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
                 if (EMB16 && !n_a32) aN[q] = emb_load(rsN_a, q);
@@ -585,9 +624,11 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
                 gaN[q] = buf_load<VW, AUX_SC1>(rsN_ga, (lane + q * 64) * VW * 4);
                 if constexpr (MOM) haN[q] = buf_load<VW, AUX_SC1>(rsN_ha, (lane + q * 64) * VW * 4);
             }
-            abN  = buf_load_f32(make_rsrc(A_bias + id, 4), 0, true);
-            gabN = buf_load_f32(make_rsrc(A_gsb + id, 4), 0, true);
-            if constexpr (MOM) habN = buf_load_f32(make_rsrc(A_m2b + id, 4), 0, true);
+            if constexpr (!FAT) {
+                abN  = buf_load_f32(make_rsrc(A_bias + id, 4), 0, true);
+                gabN = buf_load_f32(make_rsrc(A_gsb + id, 4), 0, true);
+                if constexpr (MOM) habN = buf_load_f32(make_rsrc(A_m2b + id, 4), 0, true);
+            }
         };
 
         bool open_new = true;
@@ -599,8 +640,16 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             VT b[NCH], gb[NCH], hb[NCH];
 #pragma unroll
             for (int q = 0; q < NCH; ++q) { b[q] = nb[q]; gb[q] = ngb[q]; if constexpr (MOM) hb[q] = nhb[q]; }
-            const float bb = n_bb;
-            float gbb = n_gbb, hbb = n_hbb;
+            float bb = n_bb, gbb = n_gbb, hbb = n_hbb;
+            if constexpr (FAT) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q)
+                    if (q == bl_q) {
+                        bb  = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(b[q], 0)), bl_lane));
+                        gbb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(gb[q], 0)), bl_lane));
+                        if constexpr (MOM) hbb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(hb[q], 0)), bl_lane));
+                    }
+            }
             if (open_new) {
 #pragma unroll
                 for (int q = 0; q < NCH; ++q) {
@@ -608,6 +657,15 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
                     if constexpr (MOM) ha[q] = haN[q]; else ga0[q] = gaN[q];
                 }
                 ab = abN; gab = gabN; hab = habN;
+                if constexpr (FAT) {
+#pragma unroll
+                    for (int q = 0; q < NCH; ++q)
+                        if (q == bl_q) {
+                            ab  = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(a[q], 0)), bl_lane));
+                            gab = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(ga[q], 0)), bl_lane));
+                            if constexpr (MOM) hab = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(ha[q], 0)), bl_lane));
+                        }
+                }
                 cur_id = skey < 0 ? ~skey : skey;
                 cur_hot = res_is_ctx && (p.blocked ? p.hot_enabled != 0 : skey < 0);
                 rs_a = rsN_a; rs_ga = rsN_ga; rs_ha = rsN_ha;
@@ -637,27 +695,39 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             cost_acc += (0.5 * (double)wc) * (double)ic;
             const float wlr = wc * lr;
             const __amdgpu_buffer_rsrc_t rb = emb_rsrc(B_rows, b_id);
-            const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)b_id * D, row_bytes);
-            const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)b_id * D, MOM ? row_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)b_id * DS, row_bytes);
+            const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)b_id * DS, MOM ? row_bytes : 0u);
+            // the streamed row's bias takes its step here and goes out with the row (FAT), see below for the arithmetic
+            float nbb_fat = 0.0f, ngbb_fat = 0.0f, nhbb_fat = 0.0f;
+            if constexpr (FAT) {
+                if constexpr (!MOM) { nbb_fat = bb - wc * __frsqrt_rn(gbb); ngbb_fat = gbb + wc * wc; }
+                else { float m = gbb, v = hbb; nbb_fat = bb - moment_step(wc, m, v); ngbb_fat = m; nhbb_fat = v; }
+            }
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
-                if (inr[q]) {
-                    VT ob, ogb, ohb;
+                // one store instruction per table covers the row's lanes AND the lane that holds the bias
+                const bool is_bl = FAT && q == bl_q && lane == bl_lane;
+                if (inr[q] || is_bl) {
+                    VT ob{}, ogb{}, ohb{};
+                    if (is_bl) {
+                        comp<VW>(ob, 0) = nbb_fat; comp<VW>(ogb, 0) = ngbb_fat; comp<VW>(ohb, 0) = nhbb_fat;
+                    } else {
 #pragma unroll
-                    for (int t = 0; t < VW; ++t) {
-                        const float av = comp<VW>(a[q], t), bv = comp<VW>(b[q], t);
-                        const float grad_b = wc * av, grad_a = wc * bv;
-                        if constexpr (!MOM) {
-                            const float sa = comp<VW>(ga[q], t), sb = comp<VW>(gb[q], t);
-                            comp<VW>(ob, t)    = __builtin_fmaf(-(wlr * av), __frsqrt_rn(sb), bv);
-                            comp<VW>(ogb, t)   = __builtin_fmaf(grad_b, grad_b, sb);
-                            comp<VW>(a[q], t)  = __builtin_fmaf(-(wlr * bv), __frsqrt_rn(sa), av);
-                            comp<VW>(ga[q], t) = __builtin_fmaf(grad_a, grad_a, sa);
-                        } else {
-                            float m = comp<VW>(gb[q], t), v = comp<VW>(hb[q], t);
-                            comp<VW>(ob, t) = bv - moment_step(grad_b, m, v);
-                            comp<VW>(ogb, t) = m; comp<VW>(ohb, t) = v;
-                            comp<VW>(a[q], t) = av - moment_step(grad_a, comp<VW>(ga[q], t), comp<VW>(ha[q], t));
+                        for (int t = 0; t < VW; ++t) {
+                            const float av = comp<VW>(a[q], t), bv = comp<VW>(b[q], t);
+                            const float grad_b = wc * av, grad_a = wc * bv;
+                            if constexpr (!MOM) {
+                                const float sa = comp<VW>(ga[q], t), sb = comp<VW>(gb[q], t);
+                                comp<VW>(ob, t)    = __builtin_fmaf(-(wlr * av), __frsqrt_rn(sb), bv);
+                                comp<VW>(ogb, t)   = __builtin_fmaf(grad_b, grad_b, sb);
+                                comp<VW>(a[q], t)  = __builtin_fmaf(-(wlr * bv), __frsqrt_rn(sa), av);
+                                comp<VW>(ga[q], t) = __builtin_fmaf(grad_a, grad_a, sa);
+                            } else {
+                                float m = comp<VW>(gb[q], t), v = comp<VW>(hb[q], t);
+                                comp<VW>(ob, t) = bv - moment_step(grad_b, m, v);
+                                comp<VW>(ogb, t) = m; comp<VW>(ohb, t) = v;
+                                comp<VW>(a[q], t) = av - moment_step(grad_a, comp<VW>(ga[q], t), comp<VW>(ha[q], t));
+                            }
                         }
                     }
                     emb_store(ob, rb, q);
@@ -667,7 +737,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             }
             if constexpr (!MOM) {
                 const float w2 = wc * wc;
-                if (lane == 0) {          // no learning rate on the biases (Adagrad.java:88-89)
+                if (!FAT && lane == 0) {          // no learning rate on the biases (Adagrad.java:88-89)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, bb - wc * __frsqrt_rn(gbb)), make_rsrc(B_bias + b_id, 4), 0, 0, AUX_SC1);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gbb + w2), make_rsrc(B_gsb + b_id, 4), 0, 0, AUX_SC1);
                 }
@@ -675,7 +745,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
                 gab = gab + w2;
             } else {                      // Adam.java:127-145: the biases take the same moment step with gradient wc
                 const float nbb = bb - moment_step(wc, gbb, hbb);
-                if (lane == 0) {
+                if (!FAT && lane == 0) {
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nbb), make_rsrc(B_bias + b_id, 4), 0, 0, AUX_SC1);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gbb), make_rsrc(B_gsb + b_id, 4), 0, 0, AUX_SC1);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hbb), make_rsrc(B_m2b + b_id, 4), 0, 0, AUX_SC1);
@@ -718,7 +788,8 @@ hogwild_fn pick_vw(int vw, int nch) { return vw == 4 ? pick_nch<4, OPT>(nch) : v
 // One wavefront spans a row: 64 lanes x VW floats x NCH chunks >= D.
 hogwild_fn pick_hogwild(int D, int opt, bool emb16, int *vw_out, int *nch_out) {
     const int vw = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
-    const int nch = (D + 64 * vw - 1) / (64 * vw);
+    // fp32 rows carry their bias at element [D] (fat rows): the lanes must cover D + 1 elements
+    const int nch = emb16 ? (D + 64 * vw - 1) / (64 * vw) : (D + 1 + 64 * vw - 1) / (64 * vw);
     hogwild_fn fn = emb16 ? pick_bf16(nch)
                   : opt == GE_OPT_ADAGRAD ? pick_vw<GE_OPT_ADAGRAD>(vw, nch)
                   : opt == GE_OPT_ADAM ? pick_vw<GE_OPT_ADAM>(vw, nch) : pick_vw<GE_OPT_AMSGRAD>(vw, nch);
@@ -759,6 +830,8 @@ struct ge_glove {
     int32_t *dbA = nullptr, *dbB = nullptr, *dchunk_flush = nullptr;
     int flush_every = RUN_CHUNK;
     bool emb16 = false;               // focus/context stored as bf16 (tab[] pointers then address uint16 data)
+    bool fat = false;                 // fp32 Hogwild: row tables are [rows x (D+4)] with the bias at [D]; tab[*BIAS] are null
+    int32_t ds = 0;                   // row stride of the fp32 row tables in floats (D, or D + 4 when fat)
     float *hub32 = nullptr;           // bf16 build: fp32 master rows of the hub columns
     int32_t *dhub_index = nullptr;
     std::vector<int32_t> host_hub_index;
@@ -794,10 +867,11 @@ void fill_params(const ge_glove *h, GloveParams &p, int32_t iteration) {
     // focus-side tables hold rows [row_begin,row_end): rebase so that kernels index by global row id
     const int64_t off = h->cfg.row_begin;
     if (h->emb16) p.focus = reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(p.focus) - off * h->cfg.dim);
-    else p.focus -= off * h->cfg.dim;
-    p.gsf -= off * h->cfg.dim;
-    p.fbias -= off;               p.gsfb -= off;
-    if (p.m2f) { p.m2f -= off * h->cfg.dim; p.m2fb -= off; }
+    else p.focus -= off * h->ds;
+    p.gsf -= off * h->ds;
+    if (!h->fat) { p.fbias -= off; p.gsfb -= off; }
+    if (p.m2f) { p.m2f -= off * h->ds; if (!h->fat) p.m2fb -= off; }
+    p.DS = h->ds;
     p.I = h->dI; p.J = h->dJ; p.X = h->dX; p.perm = h->dperm; p.L = h->dL; p.W = h->dW;
     p.cost_out = h->dcost;
     p.queue = reinterpret_cast<unsigned long long *>(h->dcost + 1);
@@ -875,6 +949,8 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     if (!h) return ge::fail(GE_ERR_OOM, "host allocation failed");
     h->cfg = *cfg;
     h->emb16 = emb16;
+    h->fat = cfg->mode == GE_MODE_HOGWILD && !emb16;
+    h->ds = h->fat ? cfg->dim + 4 : cfg->dim;
     h->cfg.row_begin = rb; h->cfg.row_end = re;
     h->rows = re - rb;
     h->stream = (hipStream_t)cfg->stream;
@@ -1087,6 +1163,26 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
         }
         GE_TRY(hipGetLastError());
     }
+    if (h->fat) {
+        // every fp32 row table becomes [rows x (D+4)]: row | bias | zeros; the separate bias vectors go away
+        static const int pairs[6][2] = {{GE_STATE_FOCUS, GE_STATE_FBIAS}, {GE_STATE_CONTEXT, GE_STATE_CBIAS},
+                                        {GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_FBIAS}, {GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_CBIAS},
+                                        {GE_STATE_M2_FOCUS, GE_STATE_M2_FBIAS}, {GE_STATE_M2_CONTEXT, GE_STATE_M2_CBIAS}};
+        for (const auto &pr : pairs) {
+            const int64_t nr = h->tab_count[pr[1]];
+            if (nr <= 0 || !h->tab[pr[0]]) continue;
+            float *fatp = nullptr;
+            GE_TRY(hipMalloc((void **)&fatp, sizeof(float) * (size_t)nr * (size_t)h->ds));
+            GE_TRY(hipMemsetAsync(fatp, 0, sizeof(float) * (size_t)nr * (size_t)h->ds, h->stream));
+            const unsigned gb = (unsigned)std::min<int64_t>((nr * D + 255) / 256, 16384);
+            hipLaunchKernelGGL(k_fat_scatter, dim3(gb), dim3(256), 0, h->stream, fatp, nr, h->ds, 0, D, h->tab[pr[0]]);
+            hipLaunchKernelGGL(k_fat_scatter, dim3((unsigned)std::min<int64_t>((nr + 255) / 256, 16384)), dim3(256), 0, h->stream, fatp, nr, h->ds, D, 1, h->tab[pr[1]]);
+            GE_TRY(hipGetLastError());
+            GE_TRY(hipStreamSynchronize(h->stream));
+            (void)hipFree(h->tab[pr[0]]); (void)hipFree(h->tab[pr[1]]);
+            h->tab[pr[0]] = fatp; h->tab[pr[1]] = nullptr;
+        }
+    }
     h->rng.s = ge::JavaRandom::jump(s0, (uint64_t)V * (uint64_t)(2 + 2 * D));
 
 #undef GE_TRY
@@ -1149,10 +1245,26 @@ static ge_status ge_glove_epoch_impl(ge_glove *h, int32_t iteration, double *cos
 }
 
 // bf16 build: an fp32 device copy of FOCUS or CONTEXT as the caller sees it (hub rows from their fp32 masters)
+// fat build: any table as the API shows it (rows [n x D] or a bias vector [n]) gathered out of the fat rows
+static const int FAT_HOME[GE_STATE_COUNT] = {GE_STATE_FOCUS, GE_STATE_CONTEXT, GE_STATE_FOCUS, GE_STATE_CONTEXT,
+                                             GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_CONTEXT,
+                                             GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT};
+static bool is_bias_table(int which) { return FAT_HOME[which] != which; }
 static ge_status materialize_f32(ge_glove *h, int which, float **out) {
     const int64_t n = h->tab_count[which];
     float *d = nullptr;
     GE_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)std::max<int64_t>(n, 1)));
+    if (h->fat) {
+        const bool bias = is_bias_table(which);
+        const int32_t D = h->cfg.dim;
+        const int64_t rows = bias ? n : n / D;
+        hipLaunchKernelGGL(k_fat_gather, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 16384))), dim3(256), 0, h->stream,
+                           h->tab[FAT_HOME[which]], rows, h->ds, bias ? D : 0, bias ? 1 : D, d);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipFree(d); return ge::fail(GE_ERR_HIP, "fat row gather failed: %s", hipGetErrorString(e)); }
+        *out = d;
+        return GE_OK;
+    }
     hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, h->stream,
                        reinterpret_cast<const uint16_t *>(h->tab[which]), d, n);
     if (which == GE_STATE_CONTEXT && h->n_hub > 0)
@@ -1176,7 +1288,8 @@ static ge_status extract_impl(ge_glove *h, void *out, bool f64) {
     GE_HIP(hipMalloc(&d, bytes));
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
     float *foc = h->tab[GE_STATE_FOCUS], *ctx = h->tab[GE_STATE_CONTEXT];
-    if (h->emb16) {
+    const bool temp = h->emb16 || h->fat;
+    if (temp) {
         foc = ctx = nullptr;
         ge_status s1 = materialize_f32(h, GE_STATE_FOCUS, &foc);
         ge_status s2 = s1 == GE_OK ? materialize_f32(h, GE_STATE_CONTEXT, &ctx) : s1;
@@ -1186,7 +1299,7 @@ static ge_status extract_impl(ge_glove *h, void *out, bool f64) {
     else     hipLaunchKernelGGL(k_extract<float>,  dim3(blocks), dim3(256), 0, h->stream, foc, ctx, (float *)d, n);
     hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (h->emb16) { (void)hipFree(foc); (void)hipFree(ctx); }
+    if (temp) { (void)hipFree(foc); (void)hipFree(ctx); }
     (void)hipFree(d);
     if (e != hipSuccess) return ge::fail(GE_ERR_HIP, "extract copy failed: %s", hipGetErrorString(e));
     return GE_OK;
@@ -1199,7 +1312,8 @@ ge_status ge_glove_get_state(ge_glove *h, int32_t which, float *out, int64_t cou
     if (st != GE_OK) return st;
     if (which < 0 || which >= GE_STATE_COUNT || !out) return ge::fail(GE_ERR_ARG, "invalid state id %d or null buffer", which);
     if (count != h->tab_count[which]) return ge::fail(GE_ERR_ARG, "state %d holds %lld floats, caller passed %lld", which, (long long)h->tab_count[which], (long long)count);
-    if (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT)) {
+    if (h->tab_count[which] == 0) return GE_OK;
+    if (h->fat || (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT))) {
         float *d = nullptr;
         st = materialize_f32(h, which, &d);
         if (st != GE_OK) return st;
@@ -1219,6 +1333,23 @@ ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_
     if (st != GE_OK) return st;
     if (which < 0 || which >= GE_STATE_COUNT || !in) return ge::fail(GE_ERR_ARG, "invalid state id %d or null buffer", which);
     if (count != h->tab_count[which]) return ge::fail(GE_ERR_ARG, "state %d holds %lld floats, caller passed %lld", which, (long long)h->tab_count[which], (long long)count);
+    if (count == 0) return GE_OK;
+    if (h->fat) {
+        float *d = nullptr;
+        GE_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)count));
+        hipError_t e = hipMemcpyAsync(d, in, sizeof(float) * (size_t)count, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) {
+            const bool bias = is_bias_table(which);
+            const int32_t D = h->cfg.dim;
+            hipLaunchKernelGGL(k_fat_scatter, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 16384))), dim3(256), 0, h->stream,
+                               h->tab[FAT_HOME[which]], bias ? count : count / D, h->ds, bias ? D : 0, bias ? 1 : D, d);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        }
+        (void)hipFree(d);
+        if (e != hipSuccess) return ge::fail(GE_ERR_HIP, "state copy failed: %s", hipGetErrorString(e));
+        return GE_OK;
+    }
     if (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT)) {
         float *d = nullptr;
         GE_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)std::max<int64_t>(count, 1)));
@@ -1244,6 +1375,13 @@ ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *
     if (which < 0 || which >= GE_STATE_COUNT || !dptr) return ge::fail(GE_ERR_ARG, "invalid state id %d or null out", which);
     if (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT))
         return ge::fail(GE_ERR_STATE, "table %d is stored as bf16 (+ fp32 hub rows); use ge_glove_get_state/set_state", which);
+    if (h->fat) {
+        // fat rows: the row tables are [n x row_stride] with the bias at column dim; a bias "table" is that column.
+        // *count = floats of the whole fat table; ge_glove_table_layout gives rows / stride / dim.
+        *dptr = h->tab[FAT_HOME[which]];
+        if (count) *count = (is_bias_table(which) ? h->tab_count[which] : h->tab_count[which] / h->cfg.dim) * (int64_t)h->ds;
+        return GE_OK;
+    }
     *dptr = h->tab[which];
     if (count) *count = h->tab_count[which];
     return GE_OK;
@@ -1257,6 +1395,8 @@ ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out) {
     out->hub_index = h->emb16 ? h->dhub_index : nullptr;
     out->n_hub = h->emb16 ? h->n_hub : 0;
     out->vocab_size = h->cfg.vocab_size; out->dim = h->cfg.dim;
+    out->row_stride = h->emb16 ? h->cfg.dim : h->ds;
+    out->accum = h->tab[GE_STATE_GSQ_CONTEXT];
     return GE_OK;
 }
 

@@ -30,7 +30,7 @@ SYMBOLS = (
     "ge_glove_cfg_default", "ge_glove_create", "ge_glove_epoch", "ge_glove_extract_f32",
     "ge_glove_extract_f64", "ge_glove_get_state", "ge_glove_set_state", "ge_glove_device_ptr",
     "ge_glove_epoch_order", "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
-    "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn", "ge_exchange_turn_bf16", "ge_glove_context_layout",
+    "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn", "ge_exchange_turn_rows", "ge_exchange_turn_bf16", "ge_glove_context_layout",
     "ge_sim_cfg_default", "ge_sim_cfg_size", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_device_count",
 )
 
@@ -73,7 +73,7 @@ class Strings(C.Structure):
 
 class ContextLayout(C.Structure):
     _fields_ = [("table", C.c_void_p), ("dtype", C.c_int32), ("hub_rows", C.c_void_p), ("hub_index", C.c_void_p),
-                ("n_hub", C.c_int32), ("vocab_size", C.c_int32), ("dim", C.c_int32)]
+                ("n_hub", C.c_int32), ("vocab_size", C.c_int32), ("dim", C.c_int32), ("row_stride", C.c_int32), ("accum", C.c_void_p)]
 
 
 class GeError(RuntimeError):
@@ -139,6 +139,7 @@ def lib():
     L.ge_sim_pairs_destroy.argtypes = [vp]; L.ge_sim_pairs_destroy.restype = None
     L.ge_glove_context_layout.argtypes = [vp, C.POINTER(ContextLayout)]
     L.ge_exchange_turn_bf16.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_uint32, vp]
+    L.ge_exchange_turn_rows.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
     L.ge_exchange_turn.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
     L.ge_last_error.argtypes = []; L.ge_last_error.restype = C.c_char_p
     L.ge_version.argtypes = []; L.ge_version.restype = C.c_char_p

@@ -69,6 +69,35 @@ class Bf16Context:
         return full.view(-1).contiguous()
 
 
+def context_sync_for(optimizer, device, lazy_every=4, wire="bf16", group=None):
+    """The ContextSync of one rank's trainer handle, whatever its storage: zero-copy torch views of the library's device
+    tables (ge_glove_context_layout), each under the merge rule DESIGN.md section 7 gives it.
+      fp32 rows (fat: [V x (dim+4)], bias at [dim]): context rows summed (ge_exchange_turn_rows), cBias column averaged over
+        the ranks that moved it (a strided view), the whole accumulator table -- gradSqContext with gradSqCBias in its bias
+        column -- summed every `lazy_every`-th turn;
+      bf16 rows: Bf16Context + the separate fp32 bias / accumulator tables."""
+    import ctypes as C
+    import torch
+    from . import capi
+    lay = capi.ContextLayout()
+    capi.check(capi.lib().ge_glove_context_layout(optimizer._h, C.byref(lay)))
+    V, D, DS = lay.vocab_size, lay.dim, lay.row_stride
+
+    def wrap(name):
+        ptr, cnt = optimizer.device_ptr(name)
+        return torch.as_tensor(DeviceArray(ptr, cnt), device=device)
+
+    if lay.dtype == capi.GE_DTYPE_BF16:
+        return ContextSync(sums=[], means=[wrap("cbias")], bf16_tables=[Bf16Context(optimizer, device)],
+                           lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=lazy_every, wire=wire, group=group)
+    table = torch.as_tensor(DeviceArray(lay.table, V * DS), device=device)
+    accum = torch.as_tensor(DeviceArray(lay.accum, V * DS), device=device)
+    if DS == D:                                     # plain rows: biases are tables of their own
+        return ContextSync(sums=[table], means=[wrap("cbias")], lazy_sums=[accum, wrap("gsq_cbias")], lazy_every=lazy_every, wire=wire, group=group)
+    return ContextSync(sums=[], means=[table.view(V, DS)[:, D]], row_tables=[(table, V, DS, D)], lazy_sums=[accum],
+                       lazy_every=lazy_every, wire=wire, group=group)
+
+
 class ContextSync:
     """Reconciles the replicated context-side tables after every rank has run its local pass.
 
@@ -85,7 +114,7 @@ class ContextSync:
     Works on CPU tensors with gloo (tests) and on device memory with nccl = RCCL over xGMI (bench.py).
     """
 
-    def __init__(self, sums, means, lazy_sums=(), lazy_every=4, wire="bf16", group=None, bf16_tables=()):
+    def __init__(self, sums, means, lazy_sums=(), lazy_every=4, wire="bf16", group=None, bf16_tables=(), row_tables=()):
         """lazy_sums: `sums` tables that are reconciled only every `lazy_every`-th call -- the AdaGrad accumulators:
         between syncs each rank keeps adding its own squared gradients (its steps are then at most sqrt(world)
         larger than with the global sum); the oracle simulation shows no difference in the cost trajectory
@@ -112,13 +141,16 @@ class ContextSync:
         # bf16_tables: Bf16Context objects -- context tables stored as bf16 with fp32 master rows for the hub columns
         # (GE_DTYPE_BF16).  They only go through the take / land form below (ge_exchange_turn_bf16).
         self.bf16 = list(bf16_tables)
-        if self.bf16 and self.world > 1:
+        # row_tables: (tensor, rows, row_stride, cols) -- the row part of a table of fat rows (fp32 Hogwild layout,
+        # ge_context_layout.row_stride): summed like `sums`, through ge_exchange_turn_rows; begin / finish / turn form only.
+        self.rows = list(row_tables)
+        if (self.bf16 or self.rows) and self.world > 1:
             self._entries()                             # their base is the row values NOW, before any local pass
 
     def sync(self):
         if self.world == 1:
             return
-        if self.bf16:                                   # the bf16 layout has no torch-op form: take, all-reduce, land at once
+        if self.bf16 or self.rows:                      # these layouts have no torch-op form: take, all-reduce, land at once
             self.begin()
             self.finish()
             return
@@ -181,13 +213,17 @@ class ContextSync:
             self._ent = ([dict(t=t, o=o, mean=False, lazy=False, work=None) for t, o in zip(self.sums, self.old_s)] +
                          [dict(t=t, o=o, mean=False, lazy=True, work=None) for t, o in zip(self.lazy, self.old_l)] +
                          [dict(t=t, o=o, mean=True, lazy=False, work=None) for t, o in zip(self.means, self.old_m)])
+            for k, (t, nrows, stride, cols) in enumerate(self.rows):      # first: the largest exchange gets the whole next epoch to hide under
+                self._ent.insert(k, dict(t=t, o=t.clone(), mean=False, lazy=False, work=None, rows=(int(nrows), int(stride), int(cols)), fused=True, cnt=None,
+                                      w=self.torch.empty(t.shape, dtype=self.torch.bfloat16, device=t.device),
+                                      own=self.torch.empty(t.shape, dtype=self.torch.bfloat16, device=t.device)))
             for b in self.bf16:
                 t = b.table
                 e = dict(t=t, o=b.values_f32(), mean=False, lazy=False, work=None, bf16=b, fused=True, cnt=None,
                          w=self.torch.empty_like(t), own=self.torch.empty_like(t))
                 self._ent.append(e)
             for e in self._ent:
-                if "bf16" in e:
+                if "bf16" in e or "rows" in e:
                     continue
                 t = e["t"]
                 narrow = self.wire == "bf16" and not e["mean"] and t.numel() >= (1 << 20)
@@ -200,6 +236,13 @@ class ContextSync:
     def _fused_turn(self, e, land, take):
         from . import capi                      # the HIP library; fails loudly when it has not been built
         t = e["t"]
+        if "rows" in e:
+            nrows, stride, cols = e["rows"]
+            with self.torch.cuda.device(t.device):
+                capi.check(capi.lib().ge_exchange_turn_rows(t.data_ptr(), e["o"].data_ptr(), e["w"].data_ptr(), e["own"].data_ptr(),
+                                                            nrows, stride, cols, int(land), int(take),
+                                                            self.torch.cuda.current_stream(t.device).cuda_stream))
+            return
         if "bf16" in e:
             b = e["bf16"]
             self._seed = (getattr(self, "_seed", 0x5EED) * 1664525 + 1013904223) & 0xFFFFFFFF      # same on every call site, new per turn
@@ -276,5 +319,11 @@ class ContextSync:
         for e in self._entries():
             if "bf16" in e:
                 continue        # rows live partly in per-rank fp32 master rows (hub sets differ per rank): left as landed, equal up to bf16 rounding
-            self.dist.broadcast(e["t"], src=src, group=self.group)
-            e["o"].copy_(e["t"])
+            t = e["t"]
+            if t.is_contiguous():
+                self.dist.broadcast(t, src=src, group=self.group)
+            else:                                   # a bias column of fat rows
+                tmp = t.contiguous()
+                self.dist.broadcast(tmp, src=src, group=self.group)
+                t.copy_(tmp)
+            e["o"].copy_(t)

@@ -170,7 +170,11 @@ ge_status ge_glove_extract_f64(ge_glove *h, double *out);
 ge_status ge_glove_get_state(ge_glove *h, int32_t which, float *out, int64_t count);
 ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_t count);
 /* Raw device pointer of a table (for zero-copy wrapping by the host runtime, e.g. the
- * torch.distributed/RCCL all-reduce of the context factors). Valid until destroy. */
+ * torch.distributed/RCCL all-reduce of the context factors). Valid until destroy.
+ * GE_MODE_DETERMINISTIC handles: the table as the API shows it, *count floats.  GE_MODE_HOGWILD handles with fp32 rows keep
+ * FAT rows (ge_context_layout.row_stride = dim + 4, a row's bias at [dim]): a row table id returns the fat table and
+ * *count = rows x row_stride; a bias table id returns the fat table it lives in (FBIAS -> FOCUS, GSQ_CBIAS -> GSQ_CONTEXT ...),
+ * the bias of row r being element r * row_stride + dim.  bf16 row tables are refused (ge_glove_context_layout). */
 ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *count);
 
 /* The order in which ONE worker (cfg.workers = 1) walks the nonzeros in epoch `iteration` of a HOGWILD handle:
@@ -300,8 +304,14 @@ void ge_sim_pairs_destroy(ge_sim_pairs *r);
 ge_status ge_exchange_turn(float *table, float *base, uint16_t *wire, uint16_t *own, int64_t count,
                            int32_t land, int32_t take, void *stream);
 
+/* ge_exchange_turn over the row part of a table of FAT rows (see ge_context_layout.row_stride): `rows` rows of `row_stride`
+ * floats of which the first `cols` take part; the others (the row's bias, which merges by another rule, and the padding) are
+ * left untouched and their wire / own slots zeroed on a take.  table, base, wire, own all hold rows x row_stride elements. */
+ge_status ge_exchange_turn_rows(float *table, float *base, uint16_t *wire, uint16_t *own, int64_t rows, int32_t row_stride,
+                                int32_t cols, int32_t land, int32_t take, void *stream);
+
 /* Where the context rows of a handle live on the device (for the exchange above and below).  dtype GE_DTYPE_F32:
- * `table` is float[vocab_size*dim] and the hub fields are NULL/0.  GE_DTYPE_BF16: `table` is bf16[vocab_size*dim];
+ * `table` is float[vocab_size*row_stride] and the hub fields are NULL/0.  GE_DTYPE_BF16: `table` is bf16[vocab_size*dim];
  * a column v with hub_index[v] >= 0 keeps its current value in hub_rows[hub_index[v]*dim ..] (fp32 master row; the
  * bf16 copy of such a row is stale until extraction).  Which columns are hubs is decided per handle from ITS nonzeros. */
 typedef struct {
@@ -310,6 +320,10 @@ typedef struct {
     float         *hub_rows;     /* [n_hub x dim] */
     const int32_t *hub_index;    /* [vocab_size], device memory */
     int32_t        n_hub, vocab_size, dim;
+    int32_t        row_stride;   /* floats between consecutive rows of `table` and `accum`.  GE_MODE_HOGWILD fp32 handles keep FAT
+                                    rows: row_stride = dim + 4, element [dim] of a row is its bias (cBias in `table`, gradSqCBias /
+                                    M1 in `accum`), the rest zero padding; otherwise row_stride = dim and biases are separate */
+    float         *accum;        /* gradSqContext (Adam/AMSGrad: M1context), same row layout as `table`; fp32 always */
 } ge_context_layout;
 ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out);
 

@@ -31,14 +31,8 @@ def _rank_main(rank, world, port, q, exchange, V, N):
                       workers=-64 if exchange == "overlap" else 0)        # the overlapped form leaves slots to the collective
     opt = geglove.Adagrad(geglove.CooMatrix(V, si, sj, sx, xmax), cfg, cfg.costFunction())
     dev = torch.device("cuda", 0)
-
-    def wrap(name):
-        ptr, cnt = opt.device_ptr(name)
-        return torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=dev)
-
-    ctx = wrap("context")
-    assert ctx.data_ptr() == opt.device_ptr("context")[0]                       # zero copy
-    sync = parallel.ContextSync(sums=[ctx], means=[wrap("cbias")], lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=2)
+    sync = parallel.context_sync_for(opt, dev, lazy_every=2)
+    assert sync._entries()[0]["t"].data_ptr() == opt.device_ptr("context")[0]   # zero copy: the library's own table
     costs = []
     for it in range(EPOCHS):
         c = opt.epoch(it)
@@ -49,15 +43,19 @@ def _rank_main(rank, world, port, q, exchange, V, N):
         t = torch.tensor([c], dtype=torch.float64); dist.all_reduce(t)
         costs.append(float(t.item()) / len(I))
     fused = [e["fused"] for e in sync._entries()] if exchange == "overlap" else []
-    if exchange == "overlap":
-        sync.replicate()
+    torch.cuda.synchronize()
+    c64 = opt.get_state("context").astype(np.float64)
+    pre = torch.tensor([float(c64.sum()), float(np.abs(c64).sum())], dtype=torch.float64)
+    pre_all = [torch.zeros_like(pre) for _ in range(world)]
+    dist.all_gather(pre_all, pre)
+    sync.replicate()                    # lands what is in flight (overlap) and makes the replicas bit-identical
     torch.cuda.synchronize()
     digest = torch.tensor([float(np.float64(opt.get_state(k).astype(np.float64).sum())) for k in ("context", "cbias", "gsq_context")], dtype=torch.float64)
     gathered = [torch.zeros_like(digest) for _ in range(world)]
     dist.all_gather(gathered, digest)
     fshape = opt.get_state("focus").shape[0]
     if rank == 0:
-        q.put((costs, [g.tolist() for g in gathered], fshape, rows, fused))
+        q.put((costs, [g.tolist() for g in gathered], fshape, rows, fused, [x.tolist() for x in pre_all]))
     opt.close()
     dist.destroy_process_group()
 
@@ -70,12 +68,14 @@ def test_two_ranks_share_one_gpu(gpu, exchange, V, N):
     port = _free_port()
     procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, exchange, V, N)) for r in range(2)]
     for p in procs: p.start()
-    costs, digests, fshape, rows, fused = q.get(timeout=600)
+    costs, digests, fshape, rows, fused, pre = q.get(timeout=600)
     for p in procs: p.join(timeout=120)
     assert all(p.exitcode == 0 for p in procs)
-    assert digests[0] == digests[1]                                  # replicated tables agree after every sync
+    assert digests[0] == digests[1]                                  # replicated tables are identical after replicate()
+    if exchange == "sync":                                           # ... and before it only the bf16 rounding of the last deltas apart
+        assert abs(pre[0][0] - pre[1][0]) <= 1e-5 * pre[0][1]           # difference of the sums against the sum of magnitudes
     if exchange == "overlap":
-        assert fused == [V * D >= (1 << 20), V * D >= (1 << 20), False, False]   # context, gsq_context | gsq_cbias, cbias
+        assert fused == [True, V * (D + 4) >= (1 << 20), False]                   # context rows (fat), accumulator table, cbias column
     assert fshape == (rows[1] - rows[0]) * D                         # each rank holds only its focus rows
     import oracle as O
     from geglove import synth
@@ -208,8 +208,8 @@ def _bf16_rank_main(rank, world, port, q, exchange, V, N):
         ptr, cnt = opt.device_ptr(name)
         return torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=dev)
 
-    ctx = parallel.Bf16Context(opt, dev)
-    sync = parallel.ContextSync(sums=[], means=[wrap("cbias")], bf16_tables=[ctx], lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=2)
+    sync = parallel.context_sync_for(opt, dev, lazy_every=2)
+    ctx = sync.bf16[0]
     costs = []
     for it in range(EPOCHS):
         c = opt.epoch(it)
@@ -259,3 +259,32 @@ def test_two_ranks_with_bf16_rows(gpu, exchange):
     np.testing.assert_allclose(costs, ref, rtol=0.10 if exchange == "sync" else 0.15)
     np.testing.assert_allclose(costs[-1], ref[-1], rtol=0.05)
     assert gap <= scale * 2.0 ** -8                                     # replicas: one bf16 rounding of a delta / of a stored value apart
+
+
+@pytest.mark.parametrize("rows,stride,cols", [(1000, 36, 32), (257, 204, 200), (300, 11, 7), (5, 4, 4)])
+@pytest.mark.parametrize("land,take", [(0, 1), (1, 0), (1, 1)])
+def test_exchange_turn_rows_touches_only_the_row_part(gpu, rows, stride, cols, land, take):
+    """ge_exchange_turn_rows on a table of fat rows: columns < cols behave like ge_exchange_turn, the bias column and the
+    padding keep table / base and get zero wire / own slots on a take (4-wide and scalar variants)."""
+    from geglove import capi
+    g = torch.Generator().manual_seed(rows * 7 + stride + land * 2 + take)
+    dev = torch.device("cuda", 0)
+    n = rows * stride
+    t = torch.randn(n, generator=g).to(dev); b = (t + 0.01 * torch.randn(n, generator=g).to(dev)).contiguous()
+    w = (0.02 * torch.randn(n, generator=g)).to(torch.bfloat16).to(dev); own = (0.01 * torch.randn(n, generator=g)).to(torch.bfloat16).to(dev)
+    t0, b0, w0, o0 = t.clone(), b.clone(), w.clone(), own.clone()
+    capi.check(capi.lib().ge_exchange_turn_rows(t.data_ptr(), b.data_ptr(), w.data_ptr(), own.data_ptr(), rows, stride, cols, land, take,
+                                                torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    part = (torch.arange(n, device=dev) % stride) < cols
+    d = (t0 - b0).to(torch.bfloat16)
+    r = w0.float() - o0.float()
+    t_ref = torch.where(part, t0 + r if land else t0, t0)
+    b_ref = b0 + r if land else b0
+    w_ref, o_ref = w0, o0
+    if take:
+        b_ref = b_ref + d.float()
+        w_ref = torch.where(part, d, torch.zeros_like(d)); o_ref = w_ref
+    b_ref = torch.where(part, b_ref, b0)
+    for name, got, ref in (("table", t, t_ref), ("base", b, b_ref), ("wire", w, w_ref), ("own", own, o_ref)):
+        assert torch.equal(got, ref), name

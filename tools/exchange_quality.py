@@ -43,8 +43,7 @@ def rank_main(rank, world, port, q, exchange, V, N, D, epochs):
     sync = None
     if world > 1:
         dev = torch.device("cuda", 0)
-        wrap = lambda name: torch.as_tensor(parallel.DeviceArray(*opt.device_ptr(name)), device=dev)
-        sync = parallel.ContextSync(sums=[wrap("context")], means=[wrap("cbias")], lazy_sums=[wrap("gsq_context"), wrap("gsq_cbias")], lazy_every=4)
+        sync = parallel.context_sync_for(opt, dev, lazy_every=4)
     for it in range(epochs):
         opt.epoch(it)
         if sync is not None:
