@@ -37,16 +37,26 @@ for reserve in (0, -256):
     if reserve == 0:
         opt.close()
 dev = torch.device("cuda", 0)
-for name in ("context", "gsq_context"):
-    ptr, cnt = opt.device_ptr(name)
+import ctypes as C                               # noqa: E402
+lay = capi.ContextLayout()
+capi.check(capi.lib().ge_glove_context_layout(opt._h, C.byref(lay)))
+L = capi.lib()
+for name, ptr, rows_only in (("context rows (ge_exchange_turn_rows)", lay.table, True), ("accumulator table (ge_exchange_turn)", lay.accum, False)):
+    cnt = lay.vocab_size * lay.row_stride
     t = torch.as_tensor(parallel.DeviceArray(ptr, cnt), device=dev)
     base = t.clone(); w = torch.empty(cnt, dtype=torch.bfloat16, device=dev); own = torch.empty_like(w)
-    L = capi.lib()
-    L.ge_exchange_turn(t.data_ptr(), base.data_ptr(), w.data_ptr(), own.data_ptr(), cnt, 0, 1, None)
+
+    def turn(land):
+        if rows_only:
+            capi.check(L.ge_exchange_turn_rows(t.data_ptr(), base.data_ptr(), w.data_ptr(), own.data_ptr(), lay.vocab_size, lay.row_stride, lay.dim, land, 1, None))
+        else:
+            capi.check(L.ge_exchange_turn(t.data_ptr(), base.data_ptr(), w.data_ptr(), own.data_ptr(), cnt, land, 1, None))
+
+    turn(0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
-        L.ge_exchange_turn(t.data_ptr(), base.data_ptr(), w.data_ptr(), own.data_ptr(), cnt, 1, 1, None)
+        turn(1)
     torch.cuda.synchronize()
-    print("fused exchange turn over %s (%d floats): %.2f ms; bf16 delta on the wire: %.2f GB" % (name, cnt, (time.perf_counter() - t0) / 3 * 1e3, cnt * 2 / 1e9), flush=True)
+    print("fused exchange turn over the %s, %d floats: %.2f ms; bf16 delta on the wire: %.2f GB" % (name, cnt, (time.perf_counter() - t0) / 3 * 1e3, cnt * 2 / 1e9), flush=True)
     del base, w, own
