@@ -986,7 +986,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
         if (const char *e = std::getenv("GE_GLOVE_BLOCKS_PER_CU")) h->hw_blocks_per_cu = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("GE_GLOVE_FLUSH_EVERY")) h->flush_every = std::max(1, std::atoi(e));
         h->hw_fn = pick_hogwild(D, cfg->opt, emb16, &h->hw_vw, &h->hw_nch);
-        if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 1024 for dim%%4==0, 256 for odd dim)", D); }
+        if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 1020 for dim%%4==0, 510 for other even dims, 255 for odd dims; 1024 / 512 / 256 with bf16 rows)", D); }
         // One wavefront = one sequential worker.  Never more workers than N/2048: a small matrix must
         // not degenerate into one giant stale batch (the JVM has at most #cores updates in flight).
         const int groups_per_block = 4;

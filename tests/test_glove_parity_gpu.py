@@ -96,7 +96,7 @@ def test_vector_tolerance_dblp_like_D200(gpu):
 
 @pytest.mark.parametrize("hot", ["none", "all"])
 @pytest.mark.parametrize("method", ["glove", "pglove"])
-@pytest.mark.parametrize("D", [2, 5, 50, 100, 200, 300, 512])
+@pytest.mark.parametrize("D", [2, 5, 50, 100, 200, 256, 300, 512, 1020])       # 256: the bias lane opens a second register chunk
 def test_hogwild_conflict_free_batch(gpu, method, D, hot):
     """All i distinct, all j distinct: the racy kernel has one possible result -- through the plain
     store path (hot=none) and through the atomic-add path used for hub columns (hot=all)."""
