@@ -447,3 +447,32 @@ def test_hogwild_trained_vectors_are_as_good_as_sequential(gpu):
     assert rho_alt > 0.9                                    # the comparison is meaningful
     assert rho_dev >= rho_alt - 0.02, (rho_dev, rho_alt)
     assert abs(c_dev / c_ref - 1) <= 0.03 and abs(c_alt / c_ref - 1) <= 0.03, (c_dev, c_alt, c_ref)
+
+
+@pytest.mark.parametrize("D", [6, 50, 200])
+def test_hogwild_state_round_trip_through_the_fat_rows(gpu, D):
+    """Hogwild handles keep fat rows (row | bias | padding); get_state / set_state still speak the reference's eight
+    separate arrays.  Every table written through set_state reads back bit for bit, and an epoch from that state equals
+    the oracle's from the same state (conflict-free batch, so one possible result)."""
+    V = 3000
+    I, J, X = synth.conflict_free_batch(V, 2048, seed=D)
+    cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42)
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, 0.2), cfg, cfg.costFunction())
+    rng = np.random.default_rng(D)
+    st = {}
+    for name in ("focus", "context", "fbias", "cbias", "gsq_focus", "gsq_context", "gsq_fbias", "gsq_cbias"):
+        n = V * D if name.endswith(("focus", "context")) else V
+        a = (rng.standard_normal(n) * 0.05).astype(np.float32)
+        if name.startswith("gsq"):
+            a = (1.0 + np.abs(a)).astype(np.float32)
+        opt.set_state(name, a)
+        st[name] = a
+    for name, a in st.items():
+        assert np.array_equal(opt.get_state(name), a), name
+    ref = {k: (v.reshape(V, D).copy() if v.size == V * D else v.copy()) for k, v in st.items()}
+    O.adagrad_job(D, I, J, X, 0.2, O.COST_GLOVE, ref)
+    opt.epoch(0)
+    got = {k: opt.get_state(k) for k in st}
+    assert_state_equal(got, ref, exact=False, rtol=2e-6, atol=2e-7, what="after set_state D=%d" % D)
+    lay = opt.info()
+    assert lay["groups_in_flight"] >= 1
