@@ -184,3 +184,16 @@ def test_edge_list_reader(host, tmp_path):
     other = tmp_path / "g.ttl"; other.write_text("")
     err = host.geh_graph_summary(str(cfg).encode(), str(other).encode()).decode()
     assert err.startswith("ERR") and "N-Triples" in err and ".tsv" in err
+
+
+def test_measurement_scripts_compile():
+    """tools/ and tests/tools/ hold the scripts behind the numbers in DESIGN.md; they need a GPU to run but must at least parse."""
+    import glob
+    import py_compile
+    scripts = glob.glob(os.path.join(REPO, "tools", "*.py")) + glob.glob(os.path.join(REPO, "tests", "tools", "*.py"))
+    assert len(scripts) >= 10
+    for path in scripts:
+        py_compile.compile(path, doraise=True)
+    # the scripts that load the CPU oracle live under tests/ (oracle/ is test infrastructure)
+    for path in glob.glob(os.path.join(REPO, "tools", "*.py")):
+        assert "import oracle" not in open(path).read(), path
