@@ -361,15 +361,17 @@ constexpr int KEY_PAD = 0x7FFFFFFF;       // sorts last; marks the unused tail o
 //   narrowed once, with STOCHASTIC rounding (an update of 1e-5 on a value of 0.1 is far below half a bf16 ulp and
 //   would always round away).  Hub context rows keep an fp32 master copy (hub32) that their runs read and
 //   publish into with the same atomics as in the fp32 build; they never touch the bf16 table during training.
-template <int VW, int NCH, int OPT, bool EMB16>
+template <int VW, int NCH, int OPT, bool EMB16, bool FAT>
 __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_workers) {
+    static_assert(!(EMB16 && FAT), "bf16 rows keep their biases in separate tables");
     using VT = typename Vec<VW>::T;
     static_assert(!EMB16 || VW == 4, "bf16 embeddings need dim % 4 == 0");
     constexpr bool MOM = OPT != GE_OPT_ADAGRAD;
     // FAT rows (every fp32 Hogwild table): a row is D + 4 floats, element [D] is the row's bias (in the accumulator /
     // moment tables: the bias accumulator / moment), the rest padding that stays zero.  The bias rides in the sector
     // the row's tail already occupies, so a streamed update costs four row accesses and no 4-byte ones.
-    constexpr bool FAT = !EMB16;
+    // (FAT is chosen on the host: fp32 rows whose bias lane fits the last register chunk -- a dimension that fills its 64-lane
+    // chunks exactly would need one more chunk for that one lane and keeps the separate bias tables instead.)
     uint32_t sr_state = 0x9E3779B9u * (uint32_t)(threadIdx.x + 1) + (uint32_t)blockIdx.x * 0x85EBCA6Bu + p.bij_key[0];
     // embedding-row access: fp32 build = plain 16-byte vectors; bf16 build = 8 bytes widened / narrowed here
     auto emb_rsrc = [&](float *base, int64_t id) {
@@ -764,35 +766,39 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
 using hogwild_fn = void (*)(GloveParams, int32_t);
 
 
-template <int VW, int OPT>
+template <int VW, int OPT, bool FAT>
 hogwild_fn pick_nch(int nch) {
     switch (nch) {
-        case 1: return k_adagrad_runs<VW, 1, OPT, false>;
-        case 2: return k_adagrad_runs<VW, 2, OPT, false>;
-        case 3: return k_adagrad_runs<VW, 3, OPT, false>;
-        case 4: return k_adagrad_runs<VW, 4, OPT, false>;
+        case 1: return k_adagrad_runs<VW, 1, OPT, false, FAT>;
+        case 2: return k_adagrad_runs<VW, 2, OPT, false, FAT>;
+        case 3: return k_adagrad_runs<VW, 3, OPT, false, FAT>;
+        case 4: return k_adagrad_runs<VW, 4, OPT, false, FAT>;
         default: return nullptr;
     }
 }
 hogwild_fn pick_bf16(int nch) {       // bf16 embeddings: AdaGrad, dim % 4 == 0
     switch (nch) {
-        case 1: return k_adagrad_runs<4, 1, GE_OPT_ADAGRAD, true>;
-        case 2: return k_adagrad_runs<4, 2, GE_OPT_ADAGRAD, true>;
-        case 3: return k_adagrad_runs<4, 3, GE_OPT_ADAGRAD, true>;
-        case 4: return k_adagrad_runs<4, 4, GE_OPT_ADAGRAD, true>;
+        case 1: return k_adagrad_runs<4, 1, GE_OPT_ADAGRAD, true, false>;
+        case 2: return k_adagrad_runs<4, 2, GE_OPT_ADAGRAD, true, false>;
+        case 3: return k_adagrad_runs<4, 3, GE_OPT_ADAGRAD, true, false>;
+        case 4: return k_adagrad_runs<4, 4, GE_OPT_ADAGRAD, true, false>;
         default: return nullptr;
     }
 }
+template <int OPT, bool FAT>
+hogwild_fn pick_vw(int vw, int nch) { return vw == 4 ? pick_nch<4, OPT, FAT>(nch) : vw == 2 ? pick_nch<2, OPT, FAT>(nch) : pick_nch<1, OPT, FAT>(nch); }
 template <int OPT>
-hogwild_fn pick_vw(int vw, int nch) { return vw == 4 ? pick_nch<4, OPT>(nch) : vw == 2 ? pick_nch<2, OPT>(nch) : pick_nch<1, OPT>(nch); }
+hogwild_fn pick_fat(int vw, int nch, bool fat) { return fat ? pick_vw<OPT, true>(vw, nch) : pick_vw<OPT, false>(vw, nch); }
+// fp32 rows carry their bias at element [D] (fat rows) when the lane that would hold it lies in the row's last 64-lane chunk
+inline bool fat_rows_fit(int D) { const int vw = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1; return ((D / vw) % 64) != 0; }
 // One wavefront spans a row: 64 lanes x VW floats x NCH chunks >= D.
 hogwild_fn pick_hogwild(int D, int opt, bool emb16, int *vw_out, int *nch_out) {
     const int vw = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
-    // fp32 rows carry their bias at element [D] (fat rows): the lanes must cover D + 1 elements
-    const int nch = emb16 ? (D + 64 * vw - 1) / (64 * vw) : (D + 1 + 64 * vw - 1) / (64 * vw);
+    const bool fat = !emb16 && fat_rows_fit(D);
+    const int nch = (D + 64 * vw - 1) / (64 * vw);           // the bias lane of a fat row lies inside the last chunk
     hogwild_fn fn = emb16 ? pick_bf16(nch)
-                  : opt == GE_OPT_ADAGRAD ? pick_vw<GE_OPT_ADAGRAD>(vw, nch)
-                  : opt == GE_OPT_ADAM ? pick_vw<GE_OPT_ADAM>(vw, nch) : pick_vw<GE_OPT_AMSGRAD>(vw, nch);
+                  : opt == GE_OPT_ADAGRAD ? pick_fat<GE_OPT_ADAGRAD>(vw, nch, fat)
+                  : opt == GE_OPT_ADAM ? pick_fat<GE_OPT_ADAM>(vw, nch, fat) : pick_fat<GE_OPT_AMSGRAD>(vw, nch, fat);
     *vw_out = vw; *nch_out = nch;
     return fn;
 }
@@ -949,7 +955,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     if (!h) return ge::fail(GE_ERR_OOM, "host allocation failed");
     h->cfg = *cfg;
     h->emb16 = emb16;
-    h->fat = cfg->mode == GE_MODE_HOGWILD && !emb16;
+    h->fat = cfg->mode == GE_MODE_HOGWILD && !emb16 && fat_rows_fit(cfg->dim);
     h->ds = h->fat ? cfg->dim + 4 : cfg->dim;
     h->cfg.row_begin = rb; h->cfg.row_end = re;
     h->rows = re - rb;
@@ -986,7 +992,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
         if (const char *e = std::getenv("GE_GLOVE_BLOCKS_PER_CU")) h->hw_blocks_per_cu = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("GE_GLOVE_FLUSH_EVERY")) h->flush_every = std::max(1, std::atoi(e));
         h->hw_fn = pick_hogwild(D, cfg->opt, emb16, &h->hw_vw, &h->hw_nch);
-        if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 1020 for dim%%4==0, 510 for other even dims, 255 for odd dims; 1024 / 512 / 256 with bf16 rows)", D); }
+        if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 1024 for dim%%4==0, 512 for other even dims, 256 for odd dims)", D); }
         // One wavefront = one sequential worker.  Never more workers than N/2048: a small matrix must
         // not degenerate into one giant stale batch (the JVM has at most #cores updates in flight).
         const int groups_per_block = 4;

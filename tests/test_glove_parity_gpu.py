@@ -96,7 +96,7 @@ def test_vector_tolerance_dblp_like_D200(gpu):
 
 @pytest.mark.parametrize("hot", ["none", "all"])
 @pytest.mark.parametrize("method", ["glove", "pglove"])
-@pytest.mark.parametrize("D", [2, 5, 50, 100, 200, 256, 300, 512, 1020])       # 256: the bias lane opens a second register chunk
+@pytest.mark.parametrize("D", [2, 5, 50, 100, 200, 256, 300, 512, 1020, 1024])   # 256, 512, 1024 fill their lane chunks: no fat rows there
 def test_hogwild_conflict_free_batch(gpu, method, D, hot):
     """All i distinct, all j distinct: the racy kernel has one possible result -- through the plain
     store path (hot=none) and through the atomic-add path used for hub columns (hot=all)."""
@@ -449,7 +449,7 @@ def test_hogwild_trained_vectors_are_as_good_as_sequential(gpu):
     assert abs(c_dev / c_ref - 1) <= 0.03 and abs(c_alt / c_ref - 1) <= 0.03, (c_dev, c_alt, c_ref)
 
 
-@pytest.mark.parametrize("D", [6, 50, 200])
+@pytest.mark.parametrize("D", [6, 50, 200, 256])         # 256 keeps separate bias tables (its lanes are full)
 def test_hogwild_state_round_trip_through_the_fat_rows(gpu, D):
     """Hogwild handles keep fat rows (row | bias | padding); get_state / set_state still speak the reference's eight
     separate arrays.  Every table written through set_state reads back bit for bit, and an epoch from that state equals

@@ -18,7 +18,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _rank_main(rank, world, port, q, exchange, V, N):
+def _rank_main(rank, world, port, q, exchange, V, N, D=D):
     import geglove
     from geglove import parallel, synth
     from helpers import make_config
@@ -60,13 +60,14 @@ def _rank_main(rank, world, port, q, exchange, V, N):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,V,N", [("sync", 6000, 300000), ("overlap", 6000, 300000),
-                                          ("sync", 40000, 2000000), ("overlap", 40000, 2000000)])   # 40000 x 32 floats: bf16 wire, fused device pass
-def test_two_ranks_share_one_gpu(gpu, exchange, V, N):
+@pytest.mark.parametrize("exchange,V,N,D", [("sync", 6000, 300000, 32), ("overlap", 6000, 300000, 32),
+                                            ("sync", 40000, 2000000, 32), ("overlap", 40000, 2000000, 32),   # 40000 x 32 floats: bf16 wire, fused device pass
+                                            ("overlap", 6000, 300000, 256)])                                  # dim 256: plain rows, separate bias tables
+def test_two_ranks_share_one_gpu(gpu, exchange, V, N, D):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, exchange, V, N)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, exchange, V, N, D)) for r in range(2)]
     for p in procs: p.start()
     costs, digests, fshape, rows, fused, pre = q.get(timeout=600)
     for p in procs: p.join(timeout=120)
@@ -75,7 +76,10 @@ def test_two_ranks_share_one_gpu(gpu, exchange, V, N):
     if exchange == "sync":                                           # ... and before it only the bf16 rounding of the last deltas apart
         assert abs(pre[0][0] - pre[1][0]) <= 1e-5 * pre[0][1]           # difference of the sums against the sum of magnitudes
     if exchange == "overlap":
-        assert fused == [True, V * (D + 4) >= (1 << 20), False]                   # context rows (fat), accumulator table, cbias column
+        if D % 256:
+            assert fused == [True, V * (D + 4) >= (1 << 20), False]               # context rows (fat), accumulator table, cbias column
+        else:
+            assert fused == [V * D >= (1 << 20)] * 2 + [False, False]             # plain rows: context, gsq_context | gsq_cbias, cbias
     assert fshape == (rows[1] - rows[0]) * D                         # each rank holds only its focus rows
     import oracle as O
     from geglove import synth
