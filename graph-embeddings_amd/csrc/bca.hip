@@ -15,13 +15,15 @@
 // collide on a node).  All fp64/fp32 operations are the reference's, in the reference's order
 // (-ffp-contract=off), so the values are bit-exact; the row is emitted in java.util.HashMap
 // iteration order (bucket = (k ^ k>>>16) & (cap-1); putVal appends at the bin tail, merge() links
-// new keys at the bin head and resizes before the lookup) -- treeified bins are not emulated,
-// like in the oracle.
+// new keys at the bin head and resizes before the lookup).  Rows in which a bin could grow to 8 nodes --
+// where the JDK resizes early (treeifyBin below 64 buckets) or builds a red-black tree bin -- are
+// replayed exactly by one lane (ge_jhashmap_dev.h).
 //
 // Roofline: none of HBM/MFMA -- this is latency-bound pointer chasing over a small working set; it
 // runs once per graph, against minutes for the JVM.  Measured in DESIGN.md.
 
 #include "ge_common.h"
+#include "ge_jhashmap_dev.h"
 
 #include <algorithm>
 #include <cmath>
@@ -56,6 +58,11 @@ struct BcaWork {           // per-wave workspace (struct of arrays, `hc` slots e
     int32_t *oslot;        // slot per row entry (hc/2)
     int32_t *rpos;         // reverse-BCV iteration position -> slot (hc/2)
     int32_t *rnew;         // reverse-BCV iteration position -> 1 if the key is new to the forward BCV
+    // exact java.util.HashMap replay (ge_jhashmap_dev.h), entries e = index into touched[]
+    int32_t *jkey, *jnext, *jprev, *jparent, *jleft, *jright, *jred;   // hc/2 each
+    int32_t *ordf, *ordr;  // entries in forward / reverse put order (hc/2 each)
+    int32_t *jhead, *jtree;   // per bin (hc each); jhead doubles as the bin histogram of bins_may_treeify
+    int32_t *sidx;         // slot -> entry (hc)
 };
 
 struct BcaParams {
@@ -108,10 +115,22 @@ __device__ __forceinline__ BcaWork carve(const BcaParams &p, int wave) {
     w.oslot = (int32_t *)b;                 b += 4 * half;
     w.rpos = (int32_t *)b;                  b += 4 * half;
     w.rnew = (int32_t *)b;                  b += 4 * half;
+    w.jkey = (int32_t *)b;                  b += 4 * half;
+    w.jnext = (int32_t *)b;                 b += 4 * half;
+    w.jprev = (int32_t *)b;                 b += 4 * half;
+    w.jparent = (int32_t *)b;               b += 4 * half;
+    w.jleft = (int32_t *)b;                 b += 4 * half;
+    w.jright = (int32_t *)b;                b += 4 * half;
+    w.jred = (int32_t *)b;                  b += 4 * half;
+    w.ordf = (int32_t *)b;                  b += 4 * half;
+    w.ordr = (int32_t *)b;                  b += 4 * half;
+    w.jhead = (int32_t *)b;                 b += 4 * hc;
+    w.jtree = (int32_t *)b;                 b += 4 * hc;
+    w.sidx = (int32_t *)b;                  b += 4 * hc;
     w.alist = (int32_t *)b;
     return w;
 }
-inline int64_t work_bytes(int64_t hc, int64_t ac) { return 8 * hc + 8 * (hc / 2) + 4 * hc * 6 + 4 * (hc / 2) * 4 + 4 * ac; }
+inline int64_t work_bytes(int64_t hc, int64_t ac) { return 8 * hc + 8 * (hc / 2) + 4 * hc * 6 + 4 * (hc / 2) * 4 + 4 * (hc / 2) * 9 + 4 * hc * 3 + 4 * ac; }
 
 // find the slot of `key` (must exist); wave-uniform key
 __device__ __forceinline__ int32_t table_find(const BcaWork &w, const BcaParams &p, int32_t key) {
@@ -245,6 +264,41 @@ __device__ __forceinline__ int float_compare(float a, float b) {
     return ia == ib ? 0 : (ia < ib ? -1 : 1);
 }
 
+// Could any bin of a java.util.HashMap reach 8 nodes while the map receives its keys?  idx(e) = position of entry e in
+// the order the keys enter the map (-1: not a key of it).  With the table growing by load factor alone, the key at
+// position k enters while size = k <= threshold, so at capacity c exactly the keys with idx <= 0.75 c have entered by
+// the time the table leaves that capacity: a histogram of their bins per capacity level finds the first bin that
+// reaches 8 (merge() treeifies with the 8th node, putVal with the 9th; 8 covers both).  Until that first event the
+// load-factor trajectory IS the map's trajectory, so "no level reaches 8" is exact, not a heuristic; a row that does
+// is replayed sequentially (ge_jhashmap_dev.h).  O(n) per row.  Wave-uniform result.
+template <class IDX>
+__device__ bool bins_may_treeify(const BcaParams &p, const BcaWork &w, int32_t n_touched, int32_t n_total, IDX idx) {
+    const int lane = threadIdx.x & 63;
+    bool flag = false;
+    for (int32_t c = 16; n_total >= 8; c <<= 1) {
+        const int32_t thr = (c / 4) * 3;
+        for (int i = lane; i < c; i += 64) w.jhead[i] = 0;
+        wave_sync();
+        for (int e = lane; e < n_touched; e += 64) {
+            const int32_t k = idx(e);
+            if (k >= 0 && k <= thr) {
+                const int32_t b = (int32_t)(java_hash(w.jkey[e]) & (uint32_t)(c - 1));
+                flag |= __hip_atomic_fetch_add(w.jhead + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + 1 >= 8;
+            }
+        }
+        wave_sync();
+        if (__ballot(flag) != 0 || n_total - 1 <= thr || c >= p.hc) break;
+    }
+    return __ballot(flag) != 0;
+}
+__device__ __forceinline__ gejm::Map exact_map(const BcaParams &p, const BcaWork &w) {
+    gejm::Map m;
+    m.key = w.jkey; m.next = w.jnext; m.prev = w.jprev; m.parent = w.jparent; m.left = w.jleft; m.right = w.jright; m.red = w.jred;
+    m.head = w.jhead; m.tree = w.jtree; m.max_cap = p.hc;
+    gejm::reset(m);
+    return m;
+}
+
 __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x;
@@ -269,8 +323,35 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
         if (ok) {
             // ---- reverse BCV iteration order + merge bookkeeping (directed) ----
             int32_t M = 0, cap;
+            // entries in the order their keys entered each BCV (for the exact replay), slot -> entry
+            for (int e = lane; e < n_touched; e += 64) {
+                const int32_t s = w.touched[e];
+                w.sidx[s] = e; w.jkey[e] = w.hkey[s];
+                if (w.fseq[s] >= 0) w.ordf[w.fseq[s]] = e;
+                if (w.rseq[s] >= 0) w.ordr[w.rseq[s]] = e;
+            }
+            wave_sync();
+            bool exact_overflow = false;
             if (p.directed) {
                 const int32_t cap_r = java_cap_after_puts(nr);
+                const bool rev_exact = bins_may_treeify(p, w, n_touched, nr, [&](int e) { return w.rseq[w.touched[e]]; });
+                if (rev_exact) {
+                    // the reverse BCV is a map built by putVal alone; replay it and walk its bins
+                    if (lane == 0) {
+                        gejm::Map m = exact_map(p, w);
+                        for (int32_t k = 0; k < nr && !m.overflow; ++k) gejm::put_new(m, w.ordr[k]);
+                        int32_t t = 0;
+                        if (!m.overflow)
+                            for (int32_t b = 0; b < m.cap; ++b)
+                                for (int32_t e = m.head[b]; e >= 0; e = m.next[e]) {
+                                    const int32_t s = w.touched[e];
+                                    w.rpos[t] = s; w.rnew[t] = w.fseq[s] < 0; ++t;
+                                }
+                        if (m.overflow) status = 1;
+                    }
+                    wave_sync();
+                    exact_overflow = rfl(status) == 1;
+                } else {
                 // position of each reverse entry in the reverse map's iteration order: rank of (bin, seq)
                 for (int e = lane; e < n_touched; e += 64) {
                     const int32_t s = w.touched[e];
@@ -288,6 +369,7 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
                     w.rnew[rank] = w.fseq[s] < 0;
                 }
                 wave_sync();
+                }
                 // exclusive prefix of `new` over iteration positions -> merge sequence of new keys
                 int32_t running = 0;
                 for (int base = 0; base < nr; base += 64) {
@@ -336,6 +418,37 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
                 }
                 wave_sync();
             }
+            // The forward BCV (+ the merged keys): position of a key in the order the keys entered the map = its put
+            // sequence, or nf + its merge sequence.  A row that could fill a bin is replayed exactly instead: puts in
+            // sequence, then BCV.merge over the reverse BCV's iteration order, then -- normalised rows --
+            // remove(rootNode), which in a tree bin is not a plain unlink.  okey becomes the key's iteration position;
+            // the root of a normalised row is ranked first, where the code below finds and drops it.
+            const bool fwd_exact = !exact_overflow && bins_may_treeify(p, w, n_touched, n_out, [&](int e) {
+                const int32_t fs = w.fseq[w.touched[e]];
+                return fs >= 0 ? fs : (fs <= -2 ? nf + (-fs - 2) : -1);
+            });
+            if (fwd_exact) {
+                if (lane == 0) {
+                    gejm::Map m = exact_map(p, w);
+                    for (int32_t k = 0; k < nf && !m.overflow; ++k) gejm::put_new(m, w.ordf[k]);
+                    if (p.directed)
+                        for (int32_t t = 0; t < nr && !m.overflow; ++t) gejm::merge(m, w.sidx[w.rpos[t]], w.rnew[t] >= 0);
+                    if (!m.overflow) {
+                        const bool drop = p.normalize != GE_NORM_NONE;
+                        const int32_t root_e = w.ordf[0];                    // the bookmark is the first key of the forward BCV
+                        if (drop) gejm::remove(m, root_e);
+                        for (int32_t e = 0; e < n_touched; ++e) w.okey[e] = ~0ull;
+                        unsigned long long pos = drop ? 1 : 0;
+                        if (drop) w.okey[root_e] = 0;
+                        for (int32_t b = 0; b < m.cap; ++b)
+                            for (int32_t e = m.head[b]; e >= 0; e = m.next[e]) w.okey[e] = pos++;
+                    }
+                    if (m.overflow) status = 1;
+                }
+                wave_sync();
+                exact_overflow = rfl(status) == 1;
+            }
+            if (exact_overflow) { ok = false; status = 1; }
             const int32_t n_cand = n_touched;
             // ---- normalisation needs the row in iteration order: rank every candidate ----
             const bool drop_root = p.normalize != GE_NORM_NONE;

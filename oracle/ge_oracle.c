@@ -67,16 +67,38 @@ void geo_jrand_shuffle(geo_jrand *r, int32_t *a, int32_t n) {
 }
 
 /* ------------------------------------------------------------------------- */
-/* java.util.HashMap<Integer,Float> iteration-order emulation                 */
-/* (BCV extends HashMap, J/bca/util/BCV.java:14).  Linked bins only:          */
-/* treeified bins (>= 8 keys in one bin at capacity >= 64) are NOT emulated;  */
-/* such bins keep list order here (documented deviation).          */
+/* java.util.HashMap<Integer,Float> (JDK 8) iteration-order emulation         */
+/* (BCV extends HashMap, J/bca/util/BCV.java:14; its order is the COO order,  */
+/* J/bca/BookmarkColoring.java:99-103).  Restated from the JDK 8 source:      */
+/*  - putVal appends at the bin tail; a 9th node in one bin calls treeifyBin; */
+/*  - merge() resizes BEFORE the lookup, links a new key at the bin HEAD and  */
+/*    calls treeifyBin when the bin already held >= 7 nodes (8th node);       */
+/*  - treeifyBin with table length < 64 only calls resize();                  */
+/*  - at length >= 64 the bin becomes a red-black tree of TreeNodes ordered   */
+/*    by hash; iteration still follows `next`: the tree ROOT is moved to the  */
+/*    front (moveRootToFront), a later key is linked behind its tree PARENT   */
+/*    (putTreeVal); resize splits a tree bin into lo/hi lists in `next`       */
+/*    order and untreeifies lists of <= 6 nodes (TreeNode.split);             */
+/*  - remove() of a tree node unlinks it from the chain, may untreeify a      */
+/*    small tree, and moves the new root to the front (removeTreeNode).       */
+/* Integer keys: hash = k ^ (k >>> 16) is a bijection, so two keys never tie  */
+/* on the hash and the tree order is the signed order of the hashes.          */
 /* ------------------------------------------------------------------------- */
-typedef struct { int32_t key; float val; int32_t next; } jnode;
+#define JHM_TREEIFY_THRESHOLD   8
+#define JHM_UNTREEIFY_THRESHOLD 6
+#define JHM_MIN_TREEIFY_CAPACITY 64
+
+typedef struct {
+    int32_t key; float val;
+    int32_t next;                          /* Node.next */
+    int32_t prev, parent, left, right;     /* TreeNode links (valid while the node's bin is a tree) */
+    uint8_t red;
+} jnode;
 typedef struct {
     jnode   *nodes;
     int32_t  n_nodes, cap_nodes;
     int32_t *head;
+    uint8_t *tree;       /* tree[b] != 0: the nodes of bin b are TreeNodes */
     int32_t  tabcap;     /* 0 = table == null */
     int32_t  threshold;
     int32_t  size;
@@ -86,36 +108,187 @@ static inline uint32_t jhm_hash(int32_t key) {
     uint32_t h = (uint32_t)key;            /* Integer.hashCode() == value */
     return h ^ (h >> 16);                  /* HashMap.hash() */
 }
+static inline int32_t jhm_shash(const jhm *m, int32_t e) { return (int32_t)jhm_hash(m->nodes[e].key); }  /* `int hash`, signed compares */
 
 static void jhm_init(jhm *m) { memset(m, 0, sizeof(*m)); }
-static void jhm_free(jhm *m) { free(m->nodes); free(m->head); jhm_init(m); }
+static void jhm_free(jhm *m) { free(m->nodes); free(m->head); free(m->tree); jhm_init(m); }
 static void jhm_clear(jhm *m) {
     m->n_nodes = 0; m->size = 0; m->tabcap = 0; m->threshold = 0;
 }
 
-static void jhm_resize(jhm *m) {
-    int32_t oldcap = m->tabcap;
-    int32_t newcap = oldcap ? oldcap * 2 : 16;
-    int32_t *nh = (int32_t *)malloc(sizeof(int32_t) * (size_t)newcap);
-    int32_t *nt = (int32_t *)malloc(sizeof(int32_t) * (size_t)newcap);
-    for (int32_t b = 0; b < newcap; b++) { nh[b] = -1; nt[b] = -1; }
-    /* HashMap.resize(): each old bin splits into lo/hi lists, relative order kept */
-    for (int32_t b = 0; b < oldcap; b++) {
-        int32_t e = m->head[b];
-        while (e >= 0) {
-            int32_t nx = m->nodes[e].next;
-            int32_t nb = (int32_t)(jhm_hash(m->nodes[e].key) & (uint32_t)(newcap - 1));
-            m->nodes[e].next = -1;
-            if (nt[nb] < 0) nh[nb] = e; else m->nodes[nt[nb]].next = e;
-            nt[nb] = e;
-            e = nx;
+/* ---- TreeNode: rotations and rebalancing (HashMap.TreeNode.rotateLeft/Right, balanceInsertion, balanceDeletion) ---- */
+#define N(e) (m->nodes[e])
+static int32_t jt_rotate_left(jhm *m, int32_t root, int32_t p) {
+    int32_t r, pp, rl;
+    if (p >= 0 && (r = N(p).right) >= 0) {
+        if ((rl = N(p).right = N(r).left) >= 0) N(rl).parent = p;
+        if ((pp = N(r).parent = N(p).parent) < 0) { root = r; N(r).red = 0; }
+        else if (N(pp).left == p) N(pp).left = r;
+        else N(pp).right = r;
+        N(r).left = p;
+        N(p).parent = r;
+    }
+    return root;
+}
+static int32_t jt_rotate_right(jhm *m, int32_t root, int32_t p) {
+    int32_t l, pp, lr;
+    if (p >= 0 && (l = N(p).left) >= 0) {
+        if ((lr = N(p).left = N(l).right) >= 0) N(lr).parent = p;
+        if ((pp = N(l).parent = N(p).parent) < 0) { root = l; N(l).red = 0; }
+        else if (N(pp).right == p) N(pp).right = l;
+        else N(pp).left = l;
+        N(l).right = p;
+        N(p).parent = l;
+    }
+    return root;
+}
+static int32_t jt_balance_insertion(jhm *m, int32_t root, int32_t x) {
+    N(x).red = 1;
+    for (;;) {
+        int32_t xp, xpp, xppl, xppr;
+        if ((xp = N(x).parent) < 0) { N(x).red = 0; return x; }
+        else if (!N(xp).red || (xpp = N(xp).parent) < 0) return root;
+        if (xp == (xppl = N(xpp).left)) {
+            if ((xppr = N(xpp).right) >= 0 && N(xppr).red) {
+                N(xppr).red = 0; N(xp).red = 0; N(xpp).red = 1; x = xpp;
+            } else {
+                if (x == N(xp).right) {
+                    root = jt_rotate_left(m, root, x = xp);
+                    xpp = (xp = N(x).parent) < 0 ? -1 : N(xp).parent;
+                }
+                if (xp >= 0) {
+                    N(xp).red = 0;
+                    if (xpp >= 0) { N(xpp).red = 1; root = jt_rotate_right(m, root, xpp); }
+                }
+            }
+        } else {
+            if (xppl >= 0 && N(xppl).red) {
+                N(xppl).red = 0; N(xp).red = 0; N(xpp).red = 1; x = xpp;
+            } else {
+                if (x == N(xp).left) {
+                    root = jt_rotate_right(m, root, x = xp);
+                    xpp = (xp = N(x).parent) < 0 ? -1 : N(xp).parent;
+                }
+                if (xp >= 0) {
+                    N(xp).red = 0;
+                    if (xpp >= 0) { N(xpp).red = 1; root = jt_rotate_left(m, root, xpp); }
+                }
+            }
         }
     }
-    free(nt);
-    free(m->head);
-    m->head = nh;
-    m->tabcap = newcap;
-    m->threshold = (newcap / 4) * 3;       /* 0.75 * cap, exact for cap >= 16 */
+}
+static int32_t jt_balance_deletion(jhm *m, int32_t root, int32_t x) {
+    for (;;) {
+        int32_t xp, xpl, xpr;
+        if (x < 0 || x == root) return root;
+        else if ((xp = N(x).parent) < 0) { N(x).red = 0; return x; }
+        else if (N(x).red) { N(x).red = 0; return root; }
+        else if ((xpl = N(xp).left) == x) {
+            if ((xpr = N(xp).right) >= 0 && N(xpr).red) {
+                N(xpr).red = 0; N(xp).red = 1;
+                root = jt_rotate_left(m, root, xp);
+                xpr = (xp = N(x).parent) < 0 ? -1 : N(xp).right;
+            }
+            if (xpr < 0) x = xp;
+            else {
+                int32_t sl = N(xpr).left, sr = N(xpr).right;
+                if ((sr < 0 || !N(sr).red) && (sl < 0 || !N(sl).red)) { N(xpr).red = 1; x = xp; }
+                else {
+                    if (sr < 0 || !N(sr).red) {
+                        if (sl >= 0) N(sl).red = 0;
+                        N(xpr).red = 1;
+                        root = jt_rotate_right(m, root, xpr);
+                        xpr = (xp = N(x).parent) < 0 ? -1 : N(xp).right;
+                    }
+                    if (xpr >= 0) {
+                        N(xpr).red = (xp < 0) ? 0 : N(xp).red;
+                        if ((sr = N(xpr).right) >= 0) N(sr).red = 0;
+                    }
+                    if (xp >= 0) { N(xp).red = 0; root = jt_rotate_left(m, root, xp); }
+                    x = root;
+                }
+            }
+        } else {   /* symmetric */
+            if (xpl >= 0 && N(xpl).red) {
+                N(xpl).red = 0; N(xp).red = 1;
+                root = jt_rotate_right(m, root, xp);
+                xpl = (xp = N(x).parent) < 0 ? -1 : N(xp).left;
+            }
+            if (xpl < 0) x = xp;
+            else {
+                int32_t sl = N(xpl).left, sr = N(xpl).right;
+                if ((sl < 0 || !N(sl).red) && (sr < 0 || !N(sr).red)) { N(xpl).red = 1; x = xp; }
+                else {
+                    if (sl < 0 || !N(sl).red) {
+                        if (sr >= 0) N(sr).red = 0;
+                        N(xpl).red = 1;
+                        root = jt_rotate_left(m, root, xpl);
+                        xpl = (xp = N(x).parent) < 0 ? -1 : N(xp).left;
+                    }
+                    if (xpl >= 0) {
+                        N(xpl).red = (xp < 0) ? 0 : N(xp).red;
+                        if ((sl = N(xpl).left) >= 0) N(sl).red = 0;
+                    }
+                    if (xp >= 0) { N(xp).red = 0; root = jt_rotate_right(m, root, xp); }
+                    x = root;
+                }
+            }
+        }
+    }
+}
+static int32_t jt_root(const jhm *m, int32_t e) { while (N(e).parent >= 0) e = N(e).parent; return e; }
+
+/* TreeNode.moveRootToFront: the root becomes the bin's first node; the other nodes keep their `next` order */
+static void jt_move_root_to_front(jhm *m, int32_t *tab, int32_t tabcap, int32_t root) {
+    if (root < 0 || tabcap <= 0) return;
+    const int32_t index = (int32_t)(jhm_hash(N(root).key) & (uint32_t)(tabcap - 1));
+    const int32_t first = tab[index];
+    if (root != first) {
+        int32_t rn;
+        tab[index] = root;
+        const int32_t rp = N(root).prev;
+        if ((rn = N(root).next) >= 0) N(rn).prev = rp;
+        if (rp >= 0) N(rp).next = rn;
+        if (first >= 0) N(first).prev = root;
+        N(root).next = first;
+        N(root).prev = -1;
+    }
+}
+/* TreeNode.treeify: build the tree over the chain that starts at `first` (in chain order), then moveRootToFront */
+static void jt_treeify(jhm *m, int32_t *tab, int32_t tabcap, int32_t first) {
+    int32_t root = -1;
+    for (int32_t x = first, next; x >= 0; x = next) {
+        next = N(x).next;
+        N(x).left = N(x).right = -1;
+        if (root < 0) { N(x).parent = -1; N(x).red = 0; root = x; }
+        else {
+            const int32_t h = jhm_shash(m, x);
+            for (int32_t p = root;;) {
+                const int32_t ph = jhm_shash(m, p);
+                const int dir = (ph > h) ? -1 : 1;        /* distinct Integer keys never share a hash */
+                const int32_t xp = p;
+                if ((p = (dir <= 0) ? N(p).left : N(p).right) < 0) {
+                    N(x).parent = xp;
+                    if (dir <= 0) N(xp).left = x; else N(xp).right = x;
+                    root = jt_balance_insertion(m, root, x);
+                    break;
+                }
+            }
+        }
+    }
+    jt_move_root_to_front(m, tab, tabcap, root);
+}
+/* TreeNode.find from the root */
+static int32_t jt_find(const jhm *m, int32_t root, int32_t key) {
+    const int32_t h = (int32_t)jhm_hash(key);
+    int32_t p = root;
+    while (p >= 0) {
+        const int32_t ph = jhm_shash(m, p);
+        if (ph > h) p = N(p).left;
+        else if (ph < h) p = N(p).right;
+        else return p;                                     /* equal hash <=> equal Integer */
+    }
+    return -1;
 }
 
 static int32_t jhm_new_node(jhm *m, int32_t key, float val) {
@@ -125,46 +298,205 @@ static int32_t jhm_new_node(jhm *m, int32_t key, float val) {
     }
     int32_t id = m->n_nodes++;
     m->nodes[id].key = key; m->nodes[id].val = val; m->nodes[id].next = -1;
+    m->nodes[id].prev = m->nodes[id].parent = m->nodes[id].left = m->nodes[id].right = -1; m->nodes[id].red = 0;
     return id;
+}
+
+/* TreeNode.putTreeVal for a key known to be absent: the new node is linked behind its tree parent */
+static void jt_put_tree_val(jhm *m, int32_t b, int32_t key, float val) {
+    const int32_t h = (int32_t)jhm_hash(key);
+    const int32_t root = jt_root(m, m->head[b]);
+    for (int32_t p = root;;) {
+        const int dir = (jhm_shash(m, p) > h) ? -1 : 1;
+        const int32_t xp = p;
+        if ((p = (dir <= 0) ? N(p).left : N(p).right) < 0) {
+            const int32_t x = jhm_new_node(m, key, val);      /* may move m->nodes: no cached pointers */
+            const int32_t xpn = N(xp).next;
+            N(x).next = xpn;
+            if (dir <= 0) N(xp).left = x; else N(xp).right = x;
+            N(xp).next = x;
+            N(x).parent = N(x).prev = xp;
+            if (xpn >= 0) N(xpn).prev = x;
+            jt_move_root_to_front(m, m->head, m->tabcap, jt_balance_insertion(m, root, x));
+            return;
+        }
+    }
+}
+
+/* HashMap.resize(): a list bin splits into lo/hi lists, relative order kept; a tree bin goes through TreeNode.split */
+static void jhm_resize(jhm *m) {
+    const int32_t oldcap = m->tabcap;
+    const int32_t newcap = oldcap ? oldcap * 2 : 16;
+    int32_t *nh = (int32_t *)malloc(sizeof(int32_t) * (size_t)newcap);
+    uint8_t *ntree = (uint8_t *)calloc((size_t)newcap, 1);
+    for (int32_t b = 0; b < newcap; b++) nh[b] = -1;
+    for (int32_t j = 0; j < oldcap; j++) {
+        int32_t e = m->head[j];
+        if (e < 0) continue;
+        if (N(e).next < 0) { nh[jhm_hash(N(e).key) & (uint32_t)(newcap - 1)] = e; continue; }
+        int32_t lo_h = -1, lo_t = -1, hi_h = -1, hi_t = -1, lc = 0, hc = 0;
+        const int is_tree = m->tree[j];
+        for (int32_t nx; e >= 0; e = nx) {
+            nx = N(e).next;
+            N(e).next = -1;
+            if ((jhm_hash(N(e).key) & (uint32_t)oldcap) == 0) {
+                if ((N(e).prev = lo_t) < 0) lo_h = e; else N(lo_t).next = e;
+                lo_t = e; ++lc;
+            } else {
+                if ((N(e).prev = hi_t) < 0) hi_h = e; else N(hi_t).next = e;
+                hi_t = e; ++hc;
+            }
+        }
+        if (!is_tree) { nh[j] = lo_h; nh[j + oldcap] = hi_h; continue; }
+        /* TreeNode.split */
+        if (lo_h >= 0) {
+            nh[j] = lo_h;
+            if (lc > JHM_UNTREEIFY_THRESHOLD) {        /* else untreeify: plain nodes in this order */
+                ntree[j] = 1;
+                if (hi_h >= 0) jt_treeify(m, nh, newcap, lo_h);   /* (else is already treeified) */
+            }
+        }
+        if (hi_h >= 0) {
+            nh[j + oldcap] = hi_h;
+            if (hc > JHM_UNTREEIFY_THRESHOLD) {
+                ntree[j + oldcap] = 1;
+                if (lo_h >= 0) jt_treeify(m, nh, newcap, hi_h);
+            }
+        }
+    }
+    free(m->head); free(m->tree);
+    m->head = nh; m->tree = ntree;
+    m->tabcap = newcap;
+    m->threshold = (newcap / 4) * 3;       /* 0.75 * cap, exact for cap >= 16 */
+}
+
+/* HashMap.treeifyBin: below 64 buckets it only resizes */
+static void jhm_treeify_bin(jhm *m, int32_t key) {
+    if (m->tabcap < JHM_MIN_TREEIFY_CAPACITY) { jhm_resize(m); return; }
+    const int32_t b = (int32_t)(jhm_hash(key) & (uint32_t)(m->tabcap - 1));
+    int32_t e = m->head[b], tl = -1;
+    if (e < 0) return;
+    for (; e >= 0; e = N(e).next) { N(e).prev = tl; tl = e; }        /* replacementTreeNode keeps the order */
+    m->tree[b] = 1;
+    jt_treeify(m, m->head, m->tabcap, m->head[b]);
 }
 
 static int32_t jhm_find(const jhm *m, int32_t key) {
     if (!m->tabcap) return -1;
-    int32_t e = m->head[jhm_hash(key) & (uint32_t)(m->tabcap - 1)];
+    const int32_t b = (int32_t)(jhm_hash(key) & (uint32_t)(m->tabcap - 1));
+    int32_t e = m->head[b];
+    if (e < 0) return -1;
+    if (m->tree[b]) return jt_find(m, jt_root(m, e), key);
     while (e >= 0) { if (m->nodes[e].key == key) return e; e = m->nodes[e].next; }
     return -1;
 }
 
 /* BCV.add(int,float): super.put(key, getOrDefault(key, 0f) + value)  J/bca/util/BCV.java:35-37.
- * HashMap.putVal: new keys appended at the bin TAIL; resize after ++size > threshold. */
+ * HashMap.putVal: a new key is appended at the bin TAIL (binCount >= 7 there, i.e. it is the 9th node: treeifyBin),
+ * or goes through putTreeVal; then resize when ++size > threshold. */
 static void jhm_bcv_add(jhm *m, int32_t key, float value) {
     int32_t e = jhm_find(m, key);
     if (e >= 0) { m->nodes[e].val = m->nodes[e].val + value; return; }
     if (!m->tabcap) jhm_resize(m);
-    int32_t id = jhm_new_node(m, key, 0.0f + value);
-    int32_t b = (int32_t)(jhm_hash(key) & (uint32_t)(m->tabcap - 1));
-    if (m->head[b] < 0) m->head[b] = id;
-    else { int32_t t = m->head[b]; while (m->nodes[t].next >= 0) t = m->nodes[t].next; m->nodes[t].next = id; }
+    const int32_t b = (int32_t)(jhm_hash(key) & (uint32_t)(m->tabcap - 1));
+    if (m->head[b] < 0) { const int32_t id = jhm_new_node(m, key, 0.0f + value); m->head[b] = id; }
+    else if (m->tree[b]) jt_put_tree_val(m, b, key, 0.0f + value);
+    else {
+        const int32_t id = jhm_new_node(m, key, 0.0f + value);
+        int32_t t = m->head[b], bin_count = 0;
+        while (m->nodes[t].next >= 0) { t = m->nodes[t].next; ++bin_count; }
+        m->nodes[t].next = id;
+        if (bin_count >= JHM_TREEIFY_THRESHOLD - 1) jhm_treeify_bin(m, key);
+    }
     if (++m->size > m->threshold) jhm_resize(m);
 }
 
-/* HashMap.merge(key, value, Float::sum) (JDK 8): resize BEFORE the lookup when
- * size > threshold; a new key is linked at the bin HEAD; no resize afterwards.
+/* HashMap.merge(key, value, Float::sum) (JDK 8): resize BEFORE the lookup when size > threshold; a new key goes
+ * through putTreeVal in a tree bin, else it is linked at the bin HEAD and treeifyBin runs when the bin already
+ * held >= 7 nodes (binCount counts every node of the bin here); no resize afterwards.
  * Called from BCV.merge, J/bca/util/BCV.java:105-107. */
 static void jhm_merge_sum(jhm *m, int32_t key, float value) {
     if (m->size > m->threshold || !m->tabcap) jhm_resize(m);
     int32_t e = jhm_find(m, key);
     if (e >= 0) { m->nodes[e].val = m->nodes[e].val + value; return; }  /* Float.sum(old, value) */
-    int32_t id = jhm_new_node(m, key, value);
-    int32_t b = (int32_t)(jhm_hash(key) & (uint32_t)(m->tabcap - 1));
-    m->nodes[id].next = m->head[b];
-    m->head[b] = id;
+    const int32_t b = (int32_t)(jhm_hash(key) & (uint32_t)(m->tabcap - 1));
+    if (m->head[b] >= 0 && m->tree[b]) jt_put_tree_val(m, b, key, value);
+    else {
+        int32_t bin_count = 0;
+        for (int32_t t = m->head[b]; t >= 0; t = m->nodes[t].next) ++bin_count;
+        const int32_t id = jhm_new_node(m, key, value);
+        m->nodes[id].next = m->head[b];
+        m->head[b] = id;
+        if (bin_count >= JHM_TREEIFY_THRESHOLD - 1) jhm_treeify_bin(m, key);
+    }
     ++m->size;
 }
 
+/* TreeNode.removeTreeNode(map, tab, movable = true) */
+static void jt_remove_tree_node(jhm *m, int32_t b, int32_t p) {
+    int32_t first = m->head[b], root = first, rl;
+    const int32_t succ = N(p).next, pred = N(p).prev;
+    if (pred < 0) m->head[b] = first = succ; else N(pred).next = succ;
+    if (succ >= 0) N(succ).prev = pred;
+    if (first < 0) { m->tree[b] = 0; return; }
+    if (N(root).parent >= 0) root = jt_root(m, root);
+    if (root < 0 || N(root).right < 0 || (rl = N(root).left) < 0 || N(rl).left < 0) {
+        m->tree[b] = 0;                                   /* too small: untreeify, chain order kept */
+        return;
+    }
+    const int32_t pl = N(p).left, pr = N(p).right;
+    int32_t replacement;
+    if (pl >= 0 && pr >= 0) {
+        int32_t s = pr, sl;
+        while ((sl = N(s).left) >= 0) s = sl;            /* find successor */
+        const uint8_t c = N(s).red; N(s).red = N(p).red; N(p).red = c;   /* swap colors */
+        const int32_t sr = N(s).right;
+        const int32_t pp = N(p).parent;
+        if (s == pr) { N(p).parent = s; N(s).right = p; }
+        else {
+            const int32_t sp = N(s).parent;
+            if ((N(p).parent = sp) >= 0) { if (s == N(sp).left) N(sp).left = p; else N(sp).right = p; }
+            if ((N(s).right = pr) >= 0) N(pr).parent = s;
+        }
+        N(p).left = -1;
+        if ((N(p).right = sr) >= 0) N(sr).parent = p;
+        if ((N(s).left = pl) >= 0) N(pl).parent = s;
+        if ((N(s).parent = pp) < 0) root = s;
+        else if (p == N(pp).left) N(pp).left = s;
+        else N(pp).right = s;
+        replacement = sr >= 0 ? sr : p;
+    }
+    else if (pl >= 0) replacement = pl;
+    else if (pr >= 0) replacement = pr;
+    else replacement = p;
+    if (replacement != p) {
+        const int32_t pp = N(replacement).parent = N(p).parent;
+        if (pp < 0) root = replacement;
+        else if (p == N(pp).left) N(pp).left = replacement;
+        else N(pp).right = replacement;
+        N(p).left = N(p).right = N(p).parent = -1;
+    }
+    const int32_t r = N(p).red ? root : jt_balance_deletion(m, root, replacement);
+    if (replacement == p) {                              /* detach */
+        const int32_t pp = N(p).parent;
+        N(p).parent = -1;
+        if (pp >= 0) {
+            if (p == N(pp).left) N(pp).left = -1;
+            else if (p == N(pp).right) N(pp).right = -1;
+        }
+    }
+    jt_move_root_to_front(m, m->head, m->tabcap, r);
+}
+
+/* HashMap.remove(key) -> removeNode */
 static void jhm_remove(jhm *m, int32_t key) {
     if (!m->tabcap) return;
-    int32_t b = (int32_t)(jhm_hash(key) & (uint32_t)(m->tabcap - 1));
+    const int32_t b = (int32_t)(jhm_hash(key) & (uint32_t)(m->tabcap - 1));
+    if (m->head[b] >= 0 && m->tree[b]) {
+        const int32_t p = jt_find(m, jt_root(m, m->head[b]), key);
+        if (p >= 0) { jt_remove_tree_node(m, b, p); --m->size; }
+        return;
+    }
     int32_t e = m->head[b], prev = -1;
     while (e >= 0) {
         if (m->nodes[e].key == key) {
@@ -175,6 +507,7 @@ static void jhm_remove(jhm *m, int32_t key) {
         prev = e; e = m->nodes[e].next;
     }
 }
+#undef N
 
 /* iteration: bins ascending, list order */
 #define JHM_FOREACH(m, e) \
@@ -431,6 +764,25 @@ int64_t geo_bca_single(int32_t V,
     int64_t n = 0;
     JHM_FOREACH(&bcv, e) { if (n < cap) { keys[n] = bcv.nodes[e].key; vals[n] = bcv.nodes[e].val; } n++; }
     jhm_free(&bcv); jhm_free(&rev); bca_ctx_free(&c);
+    return n;
+}
+
+/* Replays a sequence of map operations on one java.util.HashMap<Integer,Float> and returns its iteration order
+ * (known-answer tests of the order emulation).  op 0 = BCV.add(key, 1f) (HashMap.put), 1 = merge(key, 1f, Float::sum),
+ * 2 = remove(key).  *table_len = table.length afterwards, tree_bins = number of treeified bins. */
+int64_t geo_hashmap_replay(int64_t n_ops, const int32_t *ops, const int32_t *keys,
+                           int32_t *out_keys, int64_t cap, int32_t *table_len, int32_t *tree_bins) {
+    jhm m; jhm_init(&m);
+    for (int64_t k = 0; k < n_ops; k++) {
+        if (ops[k] == 0) jhm_bcv_add(&m, keys[k], 1.0f);
+        else if (ops[k] == 1) jhm_merge_sum(&m, keys[k], 1.0f);
+        else jhm_remove(&m, keys[k]);
+    }
+    int64_t n = 0;
+    JHM_FOREACH(&m, e) { if (n < cap) out_keys[n] = m.nodes[e].key; n++; }
+    if (table_len) *table_len = m.tabcap;
+    if (tree_bins) { int32_t t = 0; for (int32_t b = 0; b < m.tabcap; b++) t += (m.head[b] >= 0 && m.tree[b]); *tree_bins = t; }
+    jhm_free(&m);
     return n;
 }
 

@@ -66,6 +66,10 @@ int64_t geo_bca_single(int32_t V,
                    double alpha, double epsilon, int directed, int normalize,
                    int32_t bookmark, int32_t *keys, float *vals, int64_t cap);
 
+/* java.util.HashMap<Integer,Float> order emulation on its own (KATs): op 0 = BCV.add (put), 1 = merge, 2 = remove. */
+int64_t geo_hashmap_replay(int64_t n_ops, const int32_t *ops, const int32_t *keys,
+                           int32_t *out_keys, int64_t cap, int32_t *table_len, int32_t *tree_bins);
+
 /* ---- GloVe / pGloVe AdaGrad trainer (J/opt/Optimizer.java, J/opt/grad/Adagrad.java) ---- */
 enum { GEO_COST_GLOVE = 0, GEO_COST_PGLOVE = 1 };
 /* Configuration.OptimizationMethod: Adagrad (J/opt/grad/Adagrad.java), Adam (Adam.java), AMSGrad (AMSGrad.java) */

@@ -107,6 +107,8 @@ def lib():
                                  C.c_double, C.c_double, C.c_int, C.c_int, C.c_int32,
                                  i32p, f32p, C.c_int64]
     L.geo_bca_single.restype = C.c_int64
+    L.geo_hashmap_replay.argtypes = [C.c_int64, i32p, i32p, i32p, C.c_int64, i32p, i32p]
+    L.geo_hashmap_replay.restype = C.c_int64
     L.geo_glove_create.argtypes = [C.c_int32, C.c_int32, C.c_int64, i32p, i32p, f32p,
                                    C.c_double, C.c_int, C.c_int64, C.c_int]
     L.geo_glove_create.restype = C.c_void_p
@@ -215,6 +217,16 @@ def bca_single(V, out_csr, in_csr, alpha, epsilon, bookmark, directed=True, norm
                              _p(keys, C.c_int32), _p(vals, C.c_float), cap)
     assert 0 <= n <= cap
     return keys[:n].copy(), vals[:n].copy()
+
+
+def hashmap_replay(ops):
+    """ops: [(op, key)] with op 'put' (BCV.add), 'merge' or 'remove'.  Returns (keys in iteration order, table length, tree bins)."""
+    code = {"put": 0, "merge": 1, "remove": 2}
+    o = np.array([code[a] for a, _ in ops], np.int32); k = np.array([b for _, b in ops], np.int32)
+    out = np.zeros(max(len(ops), 1), np.int32)
+    tl = C.c_int32(0); tb = C.c_int32(0)
+    n = lib().geo_hashmap_replay(len(ops), _p(o, C.c_int32), _p(k, C.c_int32), _p(out, C.c_int32), len(out), C.byref(tl), C.byref(tb))
+    return out[:n].tolist(), tl.value, tb.value
 
 
 class Glove:

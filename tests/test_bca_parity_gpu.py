@@ -87,6 +87,56 @@ def test_dblp_like_bit_exact_and_hub_rows(gpu):
     assert np.max(np.diff(d.row_ptr)) > 48           # at least one row went through several resizes
 
 
+def test_stride16_neighbourhood_resizes_early(gpu):
+    """java.util.HashMap.treeifyBin below 64 buckets: vertex 0 with neighbours 16,32,..,128 puts nine keys into bin 0 of
+    16; the 9th calls treeifyBin, which only resizes -> row 0 is [0,32,64,96,128,16,48,80,112] (hand-derived KAT,
+    tests/test_oracle_kat.py), not the load-factor order 0,16,..,128."""
+    g = _graph(129, [(0, 16 * k) for k in range(1, 9)])
+    d = _check(g, directed=False)
+    assert d.J[d.I == 0].tolist() == [0, 32, 64, 96, 128, 16, 48, 80, 112]
+    for normalize in ("none", "unity", "counts"):
+        _check(g, directed=True, normalize=normalize)            # the reverse pass merges the same keys head-first
+        _check(g, directed=False, normalize=normalize)
+
+
+def test_merge_path_treeifies_with_the_eighth_key(gpu):
+    """HashMap.merge counts every node of the bin: in-neighbours 16,..,128 of vertex 0 reach the forward BCV {0} through
+    BCV.merge and the 8th of them in bin 0 already triggers the resize (putVal needs nine)."""
+    g = _graph(200, [(16 * k, 0) for k in range(1, 9)] + [(0, 1)])
+    _check(g, directed=True)
+    _check(g, directed=True, normalize="unity")
+
+
+@pytest.mark.parametrize("normalize", ["none", "unity", "counts"])
+@pytest.mark.parametrize("directed", [True, False])
+def test_tree_bins_are_replayed_exactly(gpu, directed, normalize):
+    """Rows whose keys share a bin at table length >= 64: the bin becomes a red-black tree (root first, later keys behind
+    their tree parent, split / untreeify on resize, removeTreeNode for the normalised rows' remove(rootNode)).
+    Strides of 64, 256 and 1024 around several hubs, plus ordinary neighbours to push the table through resizes."""
+    rng = np.random.default_rng(3)
+    V = 70000
+    edges = []
+    for hub, stride, n in [(0, 64, 40), (5, 256, 25), (9, 1024, 30), (64, 64, 14), (70, 4096, 12)]:
+        edges += [(hub, (hub + stride * k) % V) for k in range(1, n)]
+        edges += [((hub + stride * k + 7 * stride) % V, hub) for k in range(1, n // 2)]
+        edges += [(hub, int(x)) for x in rng.integers(1, 3000, 30)]
+    edges = list({(a, b) for a, b in edges if a != b})
+    g = _graph(V, [(a, b, 1.0) for a, b in edges])
+    _check(g, alpha=0.2, epsilon=1e-4, directed=directed, normalize=normalize)
+
+
+def test_regular_id_graph_bit_exact(gpu):
+    """A lattice-like graph whose neighbour ids are regular multiples (what sequentially numbered entity types give):
+    many rows meet the early resize, some the tree bins; every row must still equal the oracle's."""
+    V = 8192
+    edges = []
+    for v in range(0, V, 3):
+        edges += [(v, (v + 16 * k) % V) for k in range(1, 11)] + [(v, (v + 1) % V)]
+    g = _graph(V, [(a, b, 1.0) for a, b in set(edges) if a != b])
+    _check(g, alpha=0.1, epsilon=1e-3, directed=True)
+    _check(g, alpha=0.1, epsilon=1e-3, directed=False, normalize="unity")
+
+
 def test_self_loops_zero_weights_and_sinks(gpu):
     g = _graph(6, [(0, 0, 1.0), (0, 1, 1.0), (1, 2, 0.0), (2, 3, 1.0), (3, 2, 1.0), (4, 4, 2.0)])
     _check(g, directed=True)

@@ -92,33 +92,337 @@ def test_kat_bca_epsilon_pruning():
     assert keys.tolist() == [0] and vals.tolist() == [F(0.1)]          # 0.9/1000 < eps: paint is dropped
 
 
+class _Node:
+    __slots__ = ("key", "val", "hash", "next", "prev", "parent", "left", "right", "red", "tree")
+    def __init__(self, key, val, nxt=None):
+        self.key, self.val, self.next = key, val, nxt
+        h = key & 0xFFFFFFFF; h ^= h >> 16
+        self.hash = h - (1 << 32) if h >= (1 << 31) else h          # Java int
+        self.prev = self.parent = self.left = self.right = None; self.red = False; self.tree = False
+
+
 class PyHashMap:
-    """java.util.HashMap<Integer,Float> order model, written from the JDK 8 source independently of ge_oracle.c."""
-    def __init__(self): self.cap = 0; self.thr = 0; self.size = 0; self.bins = []
+    """java.util.HashMap<Integer,Float> order model, written from the JDK 8 source independently of ge_oracle.c
+    (object references as in the Java code): putVal / merge / removeNode, resize, treeifyBin and the TreeNode methods
+    treeify, putTreeVal, split, untreeify, removeTreeNode, moveRootToFront, balanceInsertion, balanceDeletion."""
+    TREEIFY, UNTREEIFY, MIN_TREEIFY_CAP = 8, 6, 64
+
+    def __init__(self): self.tab = None; self.thr = 0; self.size = 0
+
+    # ---- red-black helpers (static methods of HashMap.TreeNode) ----
     @staticmethod
-    def h(k): k &= 0xFFFFFFFF; return k ^ (k >> 16)
+    def _rot_left(root, p):
+        if p is not None and p.right is not None:
+            r = p.right
+            p.right = r.left
+            if r.left is not None: r.left.parent = p
+            r.parent = p.parent
+            if p.parent is None: root = r; r.red = False
+            elif p.parent.left is p: p.parent.left = r
+            else: p.parent.right = r
+            r.left = p; p.parent = r
+        return root
+
+    @staticmethod
+    def _rot_right(root, p):
+        if p is not None and p.left is not None:
+            l = p.left
+            p.left = l.right
+            if l.right is not None: l.right.parent = p
+            l.parent = p.parent
+            if p.parent is None: root = l; l.red = False
+            elif p.parent.right is p: p.parent.right = l
+            else: p.parent.left = l
+            l.right = p; p.parent = l
+        return root
+
+    @classmethod
+    def _balance_insertion(cls, root, x):
+        x.red = True
+        while True:
+            xp = x.parent
+            if xp is None: x.red = False; return x
+            if not xp.red or xp.parent is None: return root
+            xpp = xp.parent
+            if xp is xpp.left:
+                u = xpp.right
+                if u is not None and u.red: u.red = False; xp.red = False; xpp.red = True; x = xpp
+                else:
+                    if x is xp.right:
+                        x = xp; root = cls._rot_left(root, x)
+                        xp = x.parent; xpp = None if xp is None else xp.parent
+                    if xp is not None:
+                        xp.red = False
+                        if xpp is not None: xpp.red = True; root = cls._rot_right(root, xpp)
+            else:
+                u = xpp.left
+                if u is not None and u.red: u.red = False; xp.red = False; xpp.red = True; x = xpp
+                else:
+                    if x is xp.left:
+                        x = xp; root = cls._rot_right(root, x)
+                        xp = x.parent; xpp = None if xp is None else xp.parent
+                    if xp is not None:
+                        xp.red = False
+                        if xpp is not None: xpp.red = True; root = cls._rot_left(root, xpp)
+
+    @classmethod
+    def _balance_deletion(cls, root, x):
+        red = lambda n: n is not None and n.red
+        while True:
+            if x is None or x is root: return root
+            xp = x.parent
+            if xp is None: x.red = False; return x
+            if x.red: x.red = False; return root
+            if xp.left is x:
+                s = xp.right
+                if red(s):
+                    s.red = False; xp.red = True; root = cls._rot_left(root, xp)
+                    xp = x.parent; s = None if xp is None else xp.right
+                if s is None: x = xp
+                elif not red(s.left) and not red(s.right): s.red = True; x = xp
+                else:
+                    if not red(s.right):
+                        if s.left is not None: s.left.red = False
+                        s.red = True; root = cls._rot_right(root, s)
+                        xp = x.parent; s = None if xp is None else xp.right
+                    if s is not None:
+                        s.red = False if xp is None else xp.red
+                        if s.right is not None: s.right.red = False
+                    if xp is not None: xp.red = False; root = cls._rot_left(root, xp)
+                    x = root
+            else:
+                s = xp.left
+                if red(s):
+                    s.red = False; xp.red = True; root = cls._rot_right(root, xp)
+                    xp = x.parent; s = None if xp is None else xp.left
+                if s is None: x = xp
+                elif not red(s.left) and not red(s.right): s.red = True; x = xp
+                else:
+                    if not red(s.left):
+                        if s.right is not None: s.right.red = False
+                        s.red = True; root = cls._rot_left(root, s)
+                        xp = x.parent; s = None if xp is None else xp.left
+                    if s is not None:
+                        s.red = False if xp is None else xp.red
+                        if s.left is not None: s.left.red = False
+                    if xp is not None: xp.red = False; root = cls._rot_right(root, xp)
+                    x = root
+
+    @staticmethod
+    def _root_of(n):
+        while n.parent is not None: n = n.parent
+        return n
+
+    @staticmethod
+    def _move_root_to_front(tab, root):
+        if root is None or not tab: return
+        i = (len(tab) - 1) & root.hash
+        first = tab[i]
+        if root is not first:
+            tab[i] = root
+            rp, rn = root.prev, root.next
+            if rn is not None: rn.prev = rp
+            if rp is not None: rp.next = rn
+            if first is not None: first.prev = root
+            root.next = first; root.prev = None
+
+    @classmethod
+    def _treeify(cls, tab, first):
+        root = None; x = first
+        while x is not None:
+            nxt = x.next
+            x.left = x.right = None; x.tree = True
+            if root is None: x.parent = None; x.red = False; root = x
+            else:
+                p = root
+                while True:
+                    d = -1 if p.hash > x.hash else 1       # hashes of distinct Integers differ
+                    xp = p
+                    p = p.left if d <= 0 else p.right
+                    if p is None:
+                        x.parent = xp
+                        if d <= 0: xp.left = x
+                        else: xp.right = x
+                        root = cls._balance_insertion(root, x)
+                        break
+            x = nxt
+        cls._move_root_to_front(tab, root)
+
+    @staticmethod
+    def _untreeify(first):
+        q = first
+        while q is not None: q.tree = False; q.prev = q.parent = q.left = q.right = None; q = q.next
+        return first
+
+    # ---- HashMap ----
     def resize(self):
-        newcap = self.cap * 2 if self.cap else 16
-        nb = [[] for _ in range(newcap)]
-        for b in self.bins:
-            for k, v in b: nb[self.h(k) & (newcap - 1)].append([k, v])
-        self.bins, self.cap, self.thr = nb, newcap, newcap * 3 // 4
+        old = self.tab
+        oldcap = len(old) if old else 0
+        newcap = oldcap * 2 if oldcap else 16
+        self.thr = newcap * 3 // 4
+        new = [None] * newcap
+        self.tab = new
+        for j in range(oldcap):
+            e = old[j]
+            if e is None: continue
+            if e.next is None: new[e.hash & (newcap - 1)] = e; continue
+            was_tree = e.tree
+            lo, hi = [], []
+            while e is not None: (lo if (e.hash & oldcap) == 0 else hi).append(e); e = e.next
+            for lst in (lo, hi):                              # relink, order preserved
+                for a, n in enumerate(lst):
+                    n.next = lst[a + 1] if a + 1 < len(lst) else None
+                    n.prev = lst[a - 1] if a else None
+            if not was_tree:
+                new[j] = lo[0] if lo else None; new[j + oldcap] = hi[0] if hi else None
+                continue
+            for lst, idx, other in ((lo, j, hi), (hi, j + oldcap, lo)):   # TreeNode.split
+                if not lst: continue
+                if len(lst) <= self.UNTREEIFY: new[idx] = self._untreeify(lst[0])
+                else:
+                    new[idx] = lst[0]
+                    if other: self._treeify(new, lst[0])          # (else is already treeified)
+
+    def treeify_bin(self, h):
+        n = len(self.tab)
+        if n < self.MIN_TREEIFY_CAP: self.resize(); return
+        e = self.tab[(n - 1) & h]; tl = None
+        while e is not None: e.prev = tl; tl = e; e = e.next
+        self._treeify(self.tab, self.tab[(n - 1) & h])
+
     def find(self, k):
-        if not self.cap: return None
-        for e in self.bins[self.h(k) & (self.cap - 1)]:
-            if e[0] == k: return e
-    def bcv_add(self, k, v):
+        if not self.tab: return None
+        probe = _Node(k, 0)
+        e = self.tab[probe.hash & (len(self.tab) - 1)]
+        if e is not None and e.tree:
+            p = self._root_of(e)
+            while p is not None and p.key != k: p = p.left if p.hash > probe.hash else p.right
+            return p
+        while e is not None and e.key != k: e = e.next
+        return e
+
+    def _put_tree_val(self, first, node):
+        root = self._root_of(first); p = root
+        while True:
+            d = -1 if p.hash > node.hash else 1
+            xp = p
+            p = p.left if d <= 0 else p.right
+            if p is None:
+                xpn = xp.next
+                node.next = xpn; node.tree = True
+                if d <= 0: xp.left = node
+                else: xp.right = node
+                xp.next = node; node.parent = node.prev = xp
+                if xpn is not None: xpn.prev = node
+                self._move_root_to_front(self.tab, self._balance_insertion(root, node))
+                return
+
+    def bcv_add(self, k, v):                                  # BCV.add -> HashMap.put -> putVal
         e = self.find(k)
-        if e: e[1] = F(e[1] + v); return
-        if not self.cap: self.resize()
-        self.bins[self.h(k) & (self.cap - 1)].append([k, F(F(0) + v)]); self.size += 1
+        if e is not None: e.val = F(e.val + v); return
+        if not self.tab: self.resize()
+        node = _Node(k, F(F(0) + v))
+        i = node.hash & (len(self.tab) - 1)
+        p = self.tab[i]
+        if p is None: self.tab[i] = node
+        elif p.tree: self._put_tree_val(p, node)
+        else:
+            bin_count = 0
+            while p.next is not None: p = p.next; bin_count += 1
+            p.next = node
+            if bin_count >= self.TREEIFY - 1: self.treeify_bin(node.hash)
+        self.size += 1
         if self.size > self.thr: self.resize()
-    def merge_sum(self, k, v):
-        if self.size > self.thr or not self.cap: self.resize()
+
+    def merge_sum(self, k, v):                                # HashMap.merge(key, value, Float::sum)
+        if self.size > self.thr or not self.tab: self.resize()
         e = self.find(k)
-        if e: e[1] = F(e[1] + v); return
-        self.bins[self.h(k) & (self.cap - 1)].insert(0, [k, v]); self.size += 1
-    def items(self): return [(k, v) for b in self.bins for k, v in b]
+        if e is not None: e.val = F(e.val + v); return
+        node = _Node(k, v)
+        i = node.hash & (len(self.tab) - 1)
+        first = self.tab[i]
+        if first is not None and first.tree: self._put_tree_val(first, node)
+        else:
+            bin_count = 0; e = first
+            while e is not None: bin_count += 1; e = e.next
+            node.next = first; self.tab[i] = node
+            if bin_count >= self.TREEIFY - 1: self.treeify_bin(node.hash)
+        self.size += 1
+
+    def remove(self, k):                                      # HashMap.remove -> removeNode (-> removeTreeNode)
+        p = self.find(k)
+        if p is None: return
+        i = p.hash & (len(self.tab) - 1)
+        self.size -= 1
+        if not p.tree:
+            if self.tab[i] is p: self.tab[i] = p.next
+            else:
+                q = self.tab[i]
+                while q.next is not p: q = q.next
+                q.next = p.next
+            return
+        tab = self.tab
+        first = tab[i]; root = first
+        succ, pred = p.next, p.prev
+        if pred is None: tab[i] = first = succ
+        else: pred.next = succ
+        if succ is not None: succ.prev = pred
+        if first is None: return
+        if root.parent is not None: root = self._root_of(root)
+        if root is None or root.right is None or root.left is None or root.left.left is None:
+            tab[i] = self._untreeify(first); return
+        pl, pr = p.left, p.right
+        if pl is not None and pr is not None:
+            s = pr
+            while s.left is not None: s = s.left
+            s.red, p.red = p.red, s.red
+            sr, pp = s.right, p.parent
+            if s is pr: p.parent = s; s.right = p
+            else:
+                sp = s.parent
+                p.parent = sp
+                if sp is not None:
+                    if s is sp.left: sp.left = p
+                    else: sp.right = p
+                s.right = pr
+                if pr is not None: pr.parent = s
+            p.left = None
+            p.right = sr
+            if sr is not None: sr.parent = p
+            s.left = pl
+            if pl is not None: pl.parent = s
+            s.parent = pp
+            if pp is None: root = s
+            elif p is pp.left: pp.left = s
+            else: pp.right = s
+            replacement = sr if sr is not None else p
+        elif pl is not None: replacement = pl
+        elif pr is not None: replacement = pr
+        else: replacement = p
+        if replacement is not p:
+            pp = replacement.parent = p.parent
+            if pp is None: root = replacement
+            elif p is pp.left: pp.left = replacement
+            else: pp.right = replacement
+            p.left = p.right = p.parent = None
+        r = root if p.red else self._balance_deletion(root, replacement)
+        if replacement is p:
+            pp = p.parent; p.parent = None
+            if pp is not None:
+                if p is pp.left: pp.left = None
+                elif p is pp.right: pp.right = None
+        self._move_root_to_front(tab, r)
+
+    def items(self):
+        out = []
+        for e in (self.tab or []):
+            while e is not None: out.append((e.key, e.val)); e = e.next
+        return out
+
+    def replay(self, ops):
+        for op, k in ops:
+            {"put": lambda: self.bcv_add(k, F(1)), "merge": lambda: self.merge_sum(k, F(1)), "remove": lambda: self.remove(k)}[op]()
+        return [k for k, _ in self.items()]
 
 
 def py_bca(V, out, inn, alpha, eps, bookmark, directed):
@@ -170,6 +474,85 @@ def test_hashmap_resize_and_merge_order():
     exp = py_bca(61, g["out"], g["inn"], 0.1, 1e-4, 0, True)
     assert keys.tolist() == [k for k, _ in exp] and vals.tolist() == [v for _, v in exp]
     assert len(keys) == 61
+
+
+# ---------------------------------------------------------------- java.util.HashMap order KATs (JDK 8 source, hand-derived)
+def test_kat_hashmap_treeify_resize_put_path():
+    """putVal: the 9th key of one bin calls treeifyBin, which at table length 16 (< MIN_TREEIFY_CAPACITY = 64) only resizes.
+    Keys 0,16,..,128 all sit in bin 0 of 16; the resize to 32 splits them by bit 16 -> bin 0: 0,32,..,128; bin 16: 16,48,..,112.
+    Without the early resize (9 keys <= threshold 12) the order would be 0,16,32,..,128."""
+    ops = [("put", 16 * k) for k in range(9)]
+    exp = [0, 32, 64, 96, 128, 16, 48, 80, 112]
+    assert O.hashmap_replay(ops) == (exp, 32, 0)
+    assert PyHashMap().replay(ops) == exp
+    # eight keys in one bin do not trigger it
+    assert O.hashmap_replay(ops[:8]) == ([16 * k for k in range(8)], 16, 0)
+
+
+def test_kat_hashmap_treeify_resize_merge_path():
+    """merge(): binCount counts EVERY node of the bin, so the 8th key triggers treeifyBin (putVal: the 9th); new keys are
+    linked at the bin head.  put 1; merge 0,16,..,112 -> bin 0 = 112,96,..,0 -> resize to 32 splits it into
+    96,64,32,0 (bin 0) and 112,80,48,16 (bin 16); merge 128 is then linked at the head of bin 0."""
+    ops = [("put", 1)] + [("merge", 16 * k) for k in range(9)]
+    exp = [128, 96, 64, 32, 0, 1, 112, 80, 48, 16]
+    assert O.hashmap_replay(ops) == (exp, 32, 0)
+    assert PyHashMap().replay(ops) == exp
+    # seven merged keys stay a list at length 16
+    ops7 = [("put", 1)] + [("merge", 16 * k) for k in range(7)]
+    assert O.hashmap_replay(ops7) == ([96, 80, 64, 48, 32, 16, 0, 1], 16, 0)
+
+
+def test_kat_hashmap_tree_bin_at_capacity_64():
+    """Keys 0,64,..,704 share bin 0 up to table length 64.  The 9th and 10th key resize (16 -> 32 -> 64), the 11th treeifies
+    the bin: a red-black tree ordered by hash, iteration still follows `next` with the tree ROOT moved to the front.
+    Eleven ascending inserts leave the 4th key (192) as root (CLRS insertion: roots 0, 64, 64, .., 192 from the 8th insert
+    on).  The 12th key (704) becomes the right child of 640 and is linked behind its parent; the rebalancing rotates at
+    384, the root stays 192."""
+    ops = [("put", 64 * k) for k in range(12)]
+    exp = [192, 0, 64, 128, 256, 320, 384, 448, 512, 576, 640, 704]
+    assert O.hashmap_replay(ops) == (exp, 64, 1)
+    assert PyHashMap().replay(ops) == exp
+    assert O.hashmap_replay(ops[:10]) == ([64 * k for k in range(10)], 64, 0)       # ten keys: still a list
+    # a further resize splits the tree bin by bit 64: 0,128,..,640 stay (6 keys -> untreeified list, order kept with the
+    # old root 192 out of the way), 64,192,..,704 move to bin 64 -- also six -> list in `next` order: 192 first
+    ops2 = ops + [("put", 2001 + k) for k in range(37)]                              # 49 keys > threshold 48 -> 128
+    keys, cap, trees = O.hashmap_replay(ops2)
+    assert cap == 128 and trees == 0
+    assert [k for k in keys if k % 64 == 0] == [0, 128, 256, 384, 512, 640, 192, 64, 320, 448, 576, 704]
+    assert PyHashMap().replay(ops2) == keys
+
+
+def test_hashmap_order_against_independent_python_model():
+    """Random op sequences on adversarial key sets (strides of 16/64/256/4096 fill single bins; ids above 65535 bring
+    the hash's high half in), puts then merges then a remove, C oracle vs the Python model."""
+    rng = np.random.default_rng(11)
+    saw_tree = saw_untreeify = 0
+    for case in range(300):
+        stride = int(rng.choice([1, 16, 64, 256, 4096, 65536]))
+        n = int(rng.integers(5, 120))
+        base = int(rng.integers(0, 3)) * 70000
+        pool = [base + stride * int(x) for x in rng.permutation(4 * n)[:n]] + [int(x) for x in rng.integers(0, 300, n // 3)]
+        ops = [("put", k) for k in pool]
+        extra = [base + stride * int(x) for x in rng.integers(0, 5 * n, n // 2)]
+        ops += [("merge", k) for k in extra]
+        if case % 3 == 0: ops += [("remove", pool[int(rng.integers(0, len(pool)))])]
+        if case % 7 == 0: ops += [("put", 5_000_000 + k) for k in range(int(rng.integers(0, 200)))]
+        got, cap, trees = O.hashmap_replay(ops)
+        m = PyHashMap(); exp = m.replay(ops)
+        assert got == exp, (case, stride)
+        assert cap == len(m.tab)
+        saw_tree += trees > 0
+    assert saw_tree > 20                                     # the tree-bin code was really exercised
+
+
+def test_bca_stride16_neighbourhood_follows_the_early_resize():
+    """Vertex 0 with neighbours 16,32,..,128 (undirected): the BCV receives 0 first, then the neighbours ascending --
+    the put-path KAT above, through geo_bca_single."""
+    g = _graph(129, [(0, 16 * k) for k in range(1, 9)])
+    keys, _ = O.bca_single(129, g["out"], g["inn"], 0.1, 1e-3, 0, directed=False)
+    assert keys.tolist() == [0, 32, 64, 96, 128, 16, 48, 80, 112]
+    exp = py_bca(129, g["out"], g["inn"], 0.1, 1e-3, 0, False)
+    assert keys.tolist() == [k for k, _ in exp]
 
 
 @pytest.mark.parametrize("normalize", [O.NORM_UNITY, O.NORM_COUNTS])
