@@ -7,9 +7,15 @@ the timed region.  Weak scaling: every GPU owns ROWS_PER_GPU focus rows and ~NNZ
 the context factors are replicated and reconciled by an all-reduce of the per-rank deltas (RCCL) per step,
 so at 8 GPUs the job is BASELINE config C4 (5 M vertices / 1 B nonzeros / dim 200).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (HIP-event
-kernel time, algorithmic bytes 16*D+28 read + 16*D+16 written per update) and, at N=1,
-`cpu_baseline` (the oracle's Hogwild restatement of Adagrad.createJob on the host cores).
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and, at N=1,
+`cpu_baseline` (the oracle's restatement of Adagrad.createJob on the host cores, T = cores - 1 and T = 1).
+
+roofline: `achieved` = bytes the kernel's schedule has to move per launch (ge_glove_info.schedule_bytes:
+per nonzero 20 B of matrix + the streamed row pair loaded and stored, per run the resident row pair loaded and
+published) / the kernel's HIP-event time; `frac` = achieved / 8 TB/s, never above 1.  The SURVEY 8(d) figure
+(16*D+28 read + 16*D+16 written per update, as if no row stayed in registers) is reported beside it under
+`naive_schedule` -- it describes a schedule this kernel does not run.  `traffic` = HBM bytes per launch from the
+committed rocprofv3 counter passes of the same kernel and workload (profiles/traffic.json), else null.
 """
 import argparse
 import json
@@ -47,13 +53,24 @@ def parse():
     ap.add_argument("--reserve-waves", type=int, default=256,
                     help="N>1 with --exchange overlap: wavefront slots the epoch kernel leaves free for the all-reduce kernels")
     ap.add_argument("--workers", type=int, default=0, help="sequential workers (wavefronts); 0 = fill the device (cfg.workers)")
+    ap.add_argument("--layout", default="", help="comma list of ge_glove_cfg.layout_flags: fixed_cuts, plain_long_rows, interleave (default: none)")
     ap.add_argument("--accum-sync-every", type=int, default=4, help="every how many context syncs the AdaGrad accumulators are reconciled too (N>1)")
     return ap.parse_args()
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, V, D, I, J, X, xmax):
-    """Oracle (CPU restatement, kind 'port') timed on a bounded sample of the same workload.
-    Only this leg of bench.py touches oracle/."""
+    """Oracle (CPU restatement, kind 'port') timed on a bounded sample of the same workload: T = cores - 1 racing
+    threads (the reference's default, Configuration.java:71-73) and T = 1.  Only this leg of bench.py touches oracle/."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import oracle as O
     O.build()
@@ -62,25 +79,32 @@ def cpu_baseline(args, V, D, I, J, X, xmax):
     n = len(I)
     order = np.random.default_rng(1).permutation(n)        # random order, like the shuffled epoch
 
-    def run(m, warm):
+    def run(m, threads, warm):
         sel = order[:m]
-        g = O.Glove(V, D, I[sel], J[sel], X[sel], xmax, kind, seed=42, threads=cores)
+        g = O.Glove(V, D, I[sel], J[sel], X[sel], xmax, kind, seed=42, threads=threads)
         if warm:
-            g.epoch(race=True, shuffle=False)              # touch the tables, start from warm caches/pages
+            g.epoch(race=threads > 1, shuffle=False)       # touch the tables, start from warm caches/pages
         t0 = time.perf_counter()
-        g.epoch(race=True, shuffle=False)
+        g.epoch(race=threads > 1, shuffle=False)
         dt = time.perf_counter() - t0
         g.close()
         return m / dt, dt
 
-    probe = min(2_000_000, n)
-    rate, _ = run(probe, True)
-    m = int(min(n, max(probe, rate * args.cpu_seconds)))
-    rate, dt = run(m, True)
-    return {"value": rate, "unit": "pair-updates/s", "cores": cores, "kind": "port",
-            "sample": "%d nonzeros drawn at random from the same matrix (same V x D tables), 1 timed Hogwild pass after a warm-up pass, %.1f s; "
+    def leg(threads, seconds):
+        probe = min(1_000_000 if threads == 1 else 2_000_000, n)
+        rate, _ = run(probe, threads, True)
+        m = int(min(n, max(probe, rate * seconds)))
+        rate, dt = run(m, threads, True)
+        return rate, dt, m
+
+    rate_t, dt_t, m_t = leg(cores, args.cpu_seconds * 0.6)
+    rate_1, dt_1, m_1 = leg(1, args.cpu_seconds * 0.4)
+    return {"value": rate_t, "unit": "pair-updates/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "single_thread": {"value": rate_1, "cores": 1, "sample_nonzeros": m_1, "seconds": dt_1},
+            "sample": "%d nonzeros drawn at random from the same matrix (same V x D tables), 1 timed Hogwild pass with %d racing threads "
+                      "after a warm-up pass, %.1f s; then %d nonzeros with one thread, %.1f s; "
                       "C restatement of Adagrad.createJob (flat arrays: faster than the Java loop, baseline only)"
-                      % (m, dt)}
+                      % (m_t, cores, dt_t, m_1, dt_1)}
 
 
 def main():
@@ -125,7 +149,7 @@ def main():
         "bca": {"alpha": 0.1, "epsilon": 1e-3, "directed": True},
         "opt": {"method": args.opt, "tolerance": 0, "maxiter": args.steps},
         "output": {"uri": []},
-        "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot, "dtype": args.dtype,
+        "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot, "dtype": args.dtype, "layout": [x for x in args.layout.split(",") if x],
                    "workers": args.workers if args.workers else (-args.reserve_waves if (world > 1 and args.exchange == "overlap") else 0),
                    "row_range": rows if world > 1 else (0, 0)}})
     t_create = time.perf_counter()
@@ -178,23 +202,29 @@ def main():
         total_updates = float(u.item())
 
     if rank == 0:
-        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950
-        # correction + WRITE_SIZE), valid only for the exact workload they were taken on
+        info = opt.info()
+        kernel = "k_adagrad_runs<%d, %d, %s, %s, %s>" % (info["vector_width"], info["chunks_per_lane"], {"adagrad": 0, "adam": 1, "amsgrad": 2}[args.opt],
+                                                          "true" if args.dtype == "bf16" else "false",
+                                                          "true" if (args.dtype != "bf16" and (D // info["vector_width"]) % 64 != 0) else "false")
+        # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction +
+        # WRITE_SIZE); an entry counts only for the kernel instance, workload and layout it was taken on
         traffic = None
         tpath = os.path.join(REPO, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:
             try:
                 for t in json.load(open(tpath)):
-                    if (t["vocab"], t["nnz_per_gpu"], t["dim"], t["cost"]) == (V, n_local, D, args.method) and world == 1 and args.opt == "adagrad" and args.dtype == "f32":
+                    if (t.get("kernel"), t["vocab"], t["nnz_per_gpu"], t["dim"], t["cost"], t.get("layout", ""), t.get("schedule_bytes")) == \
+                            (kernel, V, n_local, D, args.method, args.layout, info["schedule_bytes"]):
                         traffic = t["traffic_bytes_per_launch"]
             except Exception:
                 traffic = None
-        # algorithmic bytes per pair-update (8f for the moment optimisers: one more row per side)
+        # SURVEY.md 8d bytes per pair-update (8f for the moment optimisers: one more row per side): the naive schedule
         read_b, write_b = (16 * D + 28, 16 * D + 16) if args.opt == "adagrad" else (24 * D + 36, 24 * D + 24)
         if args.dtype == "bf16":
             read_b, write_b = 12 * D + 28, 12 * D + 16
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-        ach = n_local * (read_b + write_b) / avg_kernel_s / 1e9          # GB/s, rank 0's kernel
+        sched = info["schedule_bytes"]
+        ach = sched / avg_kernel_s / 1e9                                  # GB/s, rank 0's kernel
         out = {
             "metric": "GloVe pair-updates/sec at dim=%d" % D,
             "value": total_updates / dt,
@@ -213,11 +243,17 @@ def main():
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "traffic": traffic,
-                         "kernel": "k_adagrad_runs", "algorithmic_bytes_per_launch": n_local * (read_b + write_b), "kernel_ms": avg_kernel_s * 1e3,
-                         "bytes_per_update": {"read": read_b, "write": write_b},
-                         "achieved_read": n_local * read_b / avg_kernel_s / 1e9,
-                         "frac_read": n_local * read_b / avg_kernel_s / 1e9 / 8000.0,
-                         "kernel_updates_per_s": n_local / avg_kernel_s},
+                         "frac_traffic": (traffic / avg_kernel_s / 1e9 / 8000.0) if traffic else None,
+                         "kernel": kernel, "kernel_ms": avg_kernel_s * 1e3,
+                         "schedule_bytes_per_launch": sched, "schedule_bytes_per_update": sched / max(n_local, 1),
+                         "runs_per_launch": info["runs"],
+                         "frac_of_measured_copy_ceiling": ach / 6290.0,           # float4 copy, MI355X_MICROARCH.md
+                         "kernel_updates_per_s": n_local / avg_kernel_s,
+                         # what SURVEY.md 8(d) counts: every update moves both row pairs through HBM (this kernel keeps one in registers)
+                         "naive_schedule": {"bytes_per_update": {"read": read_b, "write": write_b},
+                                            "bytes_per_launch": n_local * (read_b + write_b),
+                                            "equivalent_GBps": n_local * (read_b + write_b) / avg_kernel_s / 1e9,
+                                            "updates_per_s_over_read_roofline_rate": (n_local / avg_kernel_s) / (8e12 / read_b)}},
             "mean_cost_first_last": [costs[0] / n_local, costs[-1] / n_local],
             "trainer": opt.info(),
             "gen_seconds": t_gen, "create_seconds": t_create,

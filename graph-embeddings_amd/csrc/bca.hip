@@ -624,6 +624,7 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     if (!(cfg->alpha > 0) || !(cfg->epsilon > 0))
         return ge::fail(GE_ERR_ARG, "Invalid BCA parameters, alpha and epsilon are mandatory");       // Configuration.check
     if (cfg->normalize < GE_NORM_NONE || cfg->normalize > GE_NORM_COUNTS) return ge::fail(GE_ERR_ARG, "invalid normalize %d", cfg->normalize);
+    if (cfg->table_slots < 0 || cfg->pool_entries < 0) return ge::fail(GE_ERR_ARG, "table_slots / pool_entries must be >= 0");
     if (!out_nbrs->ptr || !in_nbrs->ptr) return ge::fail(GE_ERR_ARG, "null CSR pointer array");
     int32_t rb = cfg->row_begin, re = cfg->row_end;
     if (rb == 0 && re == 0) re = V;
@@ -682,9 +683,9 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     // row reports its size, none is stored), the mean row size + 25 % decides.  < 1 % extra work instead of re-running
     // the rows a wrong guess leaves out.
     bool sampled = n_rows <= 16384;
-    if (const char *e = std::getenv("GE_BCA_POOL")) { pool_cap = std::max<int64_t>(64, std::atoll(e)); sampled = true; }
+    if (cfg->pool_entries > 0) { pool_cap = std::max<int64_t>(64, cfg->pool_entries); sampled = true; }
     int32_t *d_sample = nullptr; int32_t n_sample = 0;
-    if (const char *e = std::getenv("GE_BCA_TABLE")) hc = std::max<int64_t>(64, std::atoll(e));
+    if (cfg->table_slots > 0) hc = std::max<int64_t>(64, cfg->table_slots);
     int32_t *d_pJ = nullptr; float *d_pX = nullptr; char *d_work = nullptr;
     std::vector<int32_t> h_n((size_t)n_rows);
     // Rows are written into a pool whose size is a guess; a row that does not fit still reports its size, and only

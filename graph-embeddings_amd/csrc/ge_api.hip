@@ -35,6 +35,7 @@ const char *ge_last_error(void) { return ge::last_error_buf(); }
 const char *ge_version(void) { return "geglove 0.1.0 (gfx950)"; }
 
 int32_t ge_glove_cfg_size(void) { return (int32_t)sizeof(ge_glove_cfg); }
+int32_t ge_bca_cfg_size(void) { return (int32_t)sizeof(ge_bca_cfg); }
 
 int32_t ge_device_count(void) {
     int n = 0;

@@ -15,12 +15,15 @@
 
 #include "ge_common.h"
 #include "ge_javarand.h"
+#include "ge_cost.h"
+#include "ge_layout.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -41,44 +44,26 @@ struct GloveParams {
     const double *L;       // Hogwild: per-nonzero log term  (k_cost_terms)
     const float *W;        // Hogwild: per-nonzero weight
     const int32_t *bA, *bB;   // Hogwild, blocked order: resident / streamed row id per re-ordered position
-    int64_t n_chunks;         // chunks of RUN_CHUNK nonzeros per epoch
+    int64_t n_chunks;         // chunks of <= RUN_CHUNK nonzeros per epoch
     int64_t n_hchunks;        // blocked order: the first n_hchunks chunks are hub columns (column-major)
-    int32_t blocked;          // 1: chunk c = positions [128c, 128c+128) of the re-ordered arrays
+    int32_t blocked;          // 1: chunk c = positions [cstart[c], cstart[c+1]) of the re-ordered arrays (ge_layout.h)
     int32_t hot_enabled;      // blocked order: hub chunks publish deltas with atomics
     int32_t flush_every;      // a hub run publishes its delta at least every this many nonzeros (general order)
-    const int32_t *chunk_flush;   // blocked order: the same limit per hub chunk (n_hchunks entries)
+    const int32_t *cstart;    // blocked order: first position of every chunk (n_chunks + 1 entries)
+    const int32_t *cmeta;     // blocked order: hub chunk: flush limit of its runs; row chunk: the row that publishes by delta, or -1
     double *cost_out;      // Hogwild: one double accumulator
     unsigned long long *queue;   // Hogwild: next chunk to hand out (zeroed before every launch)
     double xmax;
     int64_t N;
     int32_t D;
-    int32_t DS;            // row stride of the fp32 tables in floats: D, or D + 4 when a row carries its bias at [D] (Hogwild)
+    int32_t DS;            // row stride of the fp32 row tables in floats (>= RW; a multiple of RW when a row and its accumulator rows interleave)
+    int32_t RW;            // row width in floats: D, or D + 4 when a row carries its bias at [D] (fat rows, Hogwild)
     int32_t cost_kind;
     float lr;
     int32_t order_mode;
     uint32_t bij_mask, bij_shift;
     uint32_t bij_key[4];
 };
-
-// ---- per-nonzero constants of the cost functions -------------------------------------
-// GloveCost:  ic = s + (fB+cB) - log(X);  wc = (X > max) ? ic : (float)pow(X/max, 0.75) * ic
-// PGloveCost: ic = s + (fB+cB) - log(X/(1-X)) [fp32 division];  wc = X * ic
-// Both reduce to  ic = (float)((double)s + ((double)(fB+cB) - l)),  wc = w * ic.
-// EXACT = the deterministic kernel (libm pow, as FastMath.pow in GloveCost.java:19); the Hogwild
-// kernel forms r^0.75 as sqrt(r)*sqrt(sqrt(r)) in fp64 (<= 2 ulp of fp64 before the fp32
-// narrowing, far inside its tolerance) because pow() alone costs ~60 VGPRs of occupancy.
-template <bool EXACT>
-__device__ __forceinline__ void cost_terms(int kind, float x, double xmax, double &l, float &w) {
-    if (kind == GE_COST_GLOVE) {
-        l = log((double)x);
-        const double r = (double)x / xmax;
-        if (EXACT) w = ((double)x > xmax) ? 1.0f : (float)pow(r, 0.75);
-        else { const double q = sqrt(r); w = ((double)x > xmax) ? 1.0f : (float)(q * sqrt(q)); }
-    } else {
-        l = log((double)(x / (1.0f - x)));
-        w = x;
-    }
-}
 
 // The Hogwild kernel reads (l, w) instead of X: X never changes, so the fp64 log / sqrt run once
 // per nonzero at create time (one lane per nonzero) instead of once per update, and the update
@@ -118,19 +103,44 @@ __device__ __forceinline__ int64_t map_index(const GloveParams &p, int64_t k) {
 // Optimizer ctor, J/opt/Optimizer.java:50-57: per row i the draws are fBias, cBias, then
 // focus[i,d], context[i,d] interleaved; value = (float)(nextFloat() - 0.5) / dimension.
 // Row i starts (2+2D)*i draws into the stream: jump the LCG there, then run sequentially.
-__global__ void k_init_java(float *focus, float *context, float *fbias, float *cbias,
-                            int32_t row0, int32_t rows, int32_t D, uint64_t seed_state) {
+// The tables are written in their final layout (no dense staging copy): a side whose pointer is null is skipped (a
+// sharded handle initialises all V context rows and only its own focus rows), `stride` = floats (bf16: elements)
+// between rows, bias_col >= 0 = fat rows (bias at [bias_col], the padding behind it zeroed), else the bias vectors;
+// ROW16 = bf16 storage (round to nearest even), whose hub columns also get their fp32 master row.
+__device__ __forceinline__ uint16_t bf16_rne(float f) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+template <bool ROW16>
+__global__ void k_init_java(void *focus_, void *context_, float *fbias, float *cbias, int32_t focus_row0,
+                            int32_t row0, int32_t rows, int32_t D, int64_t stride, int32_t bias_col, int32_t row_width,
+                            uint64_t seed_state, const int32_t *hub_index, float *hub32) {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const int64_t i = (int64_t)row0 + r;
     ge::JavaRandom rng{ge::JavaRandom::jump(seed_state, (uint64_t)i * (uint64_t)(2 + 2 * D))};
     const float fd = (float)D;
-    fbias[r] = (float)((double)rng.next_float() - 0.5) / fd;
-    cbias[r] = (float)((double)rng.next_float() - 0.5) / fd;
-    float *f = focus + (int64_t)r * D, *c = context + (int64_t)r * D;
+    const float fb = (float)((double)rng.next_float() - 0.5) / fd;
+    const float cb = (float)((double)rng.next_float() - 0.5) / fd;
+    using RT = typename std::conditional<ROW16, uint16_t, float>::type;
+    RT *f = focus_ ? reinterpret_cast<RT *>(focus_) + (i - focus_row0) * stride : nullptr;
+    RT *c = context_ ? reinterpret_cast<RT *>(context_) + i * stride : nullptr;
+    float *hub = (ROW16 && c && hub32 && hub_index[i] >= 0) ? hub32 + (int64_t)hub_index[i] * D : nullptr;
     for (int32_t d = 0; d < D; ++d) {
-        f[d] = (float)((double)rng.next_float() - 0.5) / fd;
-        c[d] = (float)((double)rng.next_float() - 0.5) / fd;
+        const float fv = (float)((double)rng.next_float() - 0.5) / fd;
+        const float cv = (float)((double)rng.next_float() - 0.5) / fd;
+        if constexpr (ROW16) { if (f) f[d] = bf16_rne(fv); if (c) c[d] = bf16_rne(cv); if (hub) hub[d] = cv; }
+        else { if (f) f[d] = fv; if (c) c[d] = cv; }
+    }
+    if constexpr (!ROW16) {
+        if (bias_col >= 0) {
+            if (f) { f[bias_col] = fb; for (int32_t d = bias_col + 1; d < row_width; ++d) f[d] = 0.0f; }
+            if (c) { c[bias_col] = cb; for (int32_t d = bias_col + 1; d < row_width; ++d) c[d] = 0.0f; }
+        }
+    }
+    if (bias_col < 0) {
+        if (f) fbias[i - focus_row0] = fb;
+        if (c) cbias[i] = cb;
     }
 }
 
@@ -138,6 +148,14 @@ __global__ void k_fill(float *p, int64_t n, float v) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) p[i] = v;
+}
+// rows of an accumulator table in its final layout: columns [0, valid) = v, [valid, width) = 0 (fat-row padding)
+__global__ void k_fill_rows(float *p, int64_t rows, int64_t stride, int32_t valid, int32_t width, float v) {
+    const int64_t n = rows * width, step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+        const int64_t r = i / width; const int32_t c = (int32_t)(i - r * width);
+        p[r * stride + c] = c < valid ? v : 0.0f;
+    }
 }
 
 // Optimizer.extractResult: (focus + context) / 2 in fp32, widened on store for the f64 form.
@@ -376,7 +394,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
     // embedding-row access: fp32 build = plain 16-byte vectors; bf16 build = 8 bytes widened / narrowed here
     auto emb_rsrc = [&](float *base, int64_t id) {
         if constexpr (EMB16) return make_rsrc(reinterpret_cast<uint16_t *>(base) + id * p.D, (uint32_t)p.D * 2u);
-        else return make_rsrc(base + id * p.DS, (uint32_t)p.DS * 4u);
+        else return make_rsrc(base + id * p.DS, (uint32_t)p.RW * 4u);
     };
     auto emb_load = [&](__amdgpu_buffer_rsrc_t rs, int q) -> VT {
         if constexpr (EMB16) {
@@ -412,7 +430,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
     const int lane = threadIdx.x & 63;
     const int32_t D = p.D;
     const int32_t DS = p.DS;
-    const uint32_t row_bytes = (uint32_t)DS * 4u;
+    const uint32_t row_bytes = (uint32_t)p.RW * 4u;
     const int bl_q = (D / VW) >> 6, bl_lane = (D / VW) & 63;     // FAT: the lane and register chunk that hold element [D]
     const float lr = p.lr;
     const int wave = rfl((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
@@ -441,19 +459,23 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
         double ll[2];
         int64_t chunk = tk;
         bool res_is_ctx = true;
+        int32_t c_lo = 0, c_len = 0, c_meta = -1;
         if (p.blocked) {
             uint32_t x = (uint32_t)tk;
             if (p.order_mode == ORDER_BIJECTION) { do { x = bij_round(x, p); } while ((int64_t)x >= n_chunks); }
             chunk = rfl((int)x);
             res_is_ctx = chunk < p.n_hchunks;
+            c_lo = rfl(p.cstart[chunk]); c_len = rfl(p.cstart[chunk + 1]) - c_lo; c_meta = rfl(p.cmeta[chunk]);
         }
+        // a hub run is cut every flush_lim nonzeros; a long row's piece (c_meta = its id) runs whole
+        const int32_t flush_lim = p.blocked ? (res_is_ctx ? c_meta : RUN_CHUNK) : p.flush_every;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int64_t k = chunk * RUN_CHUNK + q * 64 + lane;
+            const int64_t k = (p.blocked ? (int64_t)c_lo : chunk * RUN_CHUNK) + q * 64 + lane;
             key[q] = KEY_PAD; oth[q] = 0; ww[q] = 0.0f; ll[q] = 0.0;
             slot[q] = q * 64 + lane;
             if (p.blocked) {
-                key[q] = p.bA[k]; oth[q] = p.bB[k]; ww[q] = p.W[k]; ll[q] = p.L[k];
+                if (q * 64 + lane < c_len) { key[q] = p.bA[k]; oth[q] = p.bB[k]; ww[q] = p.W[k]; ll[q] = p.L[k]; }
             } else if (k < p.N) {
                 const int64_t idx = map_index(p, k);
                 key[q] = p.J[idx]; oth[q] = p.I[idx]; ww[q] = p.W[idx]; ll[q] = p.L[idx];
@@ -508,28 +530,50 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
         __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A_rows, 0), rs_ga = rs_a, rs_ha = rs_a;
 
         auto close_run = [&]() {
-            // Adam / AMSGrad take steps of about the learning rate whatever the gradient's size, so concurrent hub
-            // runs must not ADD their moves (measured: the cost climbs again after a few epochs); they are merged
-            // last-writer-wins, parameters and moments alike, which is exactly the Java race.  The run is still cut
-            // and re-read every flush_every nonzeros, so workers on one hub stay within that many updates of
-            // each other.
-            if (!cur_hot || MOM) {
+            // How a run's result leaves the registers:
+            //   STORE   the run owns its rows (whole focus rows of a row chunk; every run of the general order on an
+            //           ordinary column): rows, accumulators and bias are stored.
+            //   ATOMIC  the row is shared with other workers (hub column, piece of a long focus row) and takes float
+            //           atomics: the run's DELTA is added, so no worker overwrites another worker's run.
+            //   RMW     a shared FOCUS row that cannot take float atomics (bf16 storage; Adam / AMSGrad): the row is re-read,
+            //           the delta added and the sum stored -- the race window shrinks from the run to these few instructions.
+            // Adam / AMSGrad take steps of about the learning rate whatever the gradient's size, so concurrent HUB runs must
+            // not ADD their moves (measured: the cost climbs again after a few epochs); they are merged last-writer-wins,
+            // parameters and moments alike, which is exactly the Java race.  The run is still cut and re-read every
+            // flush_lim nonzeros, so workers on one hub stay within that many updates of each other.
+            const bool store_all = !cur_hot || (MOM && res_is_ctx);
+            const bool rmw_row = !store_all && !res_is_ctx && (MOM || (EMB16 && !cur_a32));
+            if (store_all || (rmw_row && MOM)) {
                 if constexpr (FAT) {                       // the bias goes out with its row
 #pragma unroll
                     for (int q = 0; q < NCH; ++q)
                         if (q == bl_q && lane == bl_lane) {
-                            comp<VW>(a[q], 0) = ab; comp<VW>(ga[q], 0) = gab;
+                            if (store_all) comp<VW>(a[q], 0) = ab;
+                            comp<VW>(ga[q], 0) = gab;
                             if constexpr (MOM) comp<VW>(ha[q], 0) = hab;
                         }
                 }
 #pragma unroll
                 for (int q = 0; q < NCH; ++q) {
-                    if (EMB16 && !cur_a32) emb_store(a[q], rs_a, q);
-                    else buf_store<VW>(a[q], rs_a, (lane + q * 64) * VW * 4);
+                    if (store_all) {
+                        if (EMB16 && !cur_a32) emb_store(a[q], rs_a, q);
+                        else buf_store<VW>(a[q], rs_a, (lane + q * 64) * VW * 4);
+                    }
                     buf_store<VW>(ga[q], rs_ga, (lane + q * 64) * VW * 4);
                     if constexpr (MOM) buf_store<VW>(ha[q], rs_ha, (lane + q * 64) * VW * 4);
                 }
-            } else {
+            }
+            if (rmw_row) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    VT cur = (EMB16 && !cur_a32) ? emb_load(rs_a, q) : buf_load<VW, AUX_SC1>(rs_a, (lane + q * 64) * VW * 4);
+#pragma unroll
+                    for (int t = 0; t < VW; ++t) comp<VW>(cur, t) += comp<VW>(a[q], t) - comp<VW>(a0[q], t);
+                    if (EMB16 && !cur_a32) emb_store(cur, rs_a, q);
+                    else buf_store<VW>(cur, rs_a, (lane + q * 64) * VW * 4);
+                }
+            }
+            if (!store_all && !MOM) {
                 // Publish the run's delta with float atomics.  Lane L holds elements [VW*L, VW*L+VW);
                 // staged through this wave's LDS strip so that every atomic wave-instruction covers 64
                 // CONSECUTIVE dwords (256 B = four 64-B memory-side requests instead of sixteen).
@@ -540,35 +584,29 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
 #pragma unroll
                     for (int t = 0; t < VW; ++t) {
                         comp<VW>(dc, t) = comp<VW>(a[q], t) - comp<VW>(a0[q], t);
-                        if constexpr (!MOM) comp<VW>(dg, t) = comp<VW>(ga[q], t) - comp<VW>(ga0[q], t);
+                        comp<VW>(dg, t) = comp<VW>(ga[q], t) - comp<VW>(ga0[q], t);
                     }
-                    *reinterpret_cast<VT *>(tr_c + (lane + q * 64) * VW) = dc;
-                    if constexpr (!MOM) *reinterpret_cast<VT *>(tr_g + (lane + q * 64) * VW) = dg;
-                    // Adam / AMSGrad moments are running averages, not sums: concurrent hub runs merge them
-                    // last-writer-wins (like the biases); only the parameter row is published additively.
-                    if constexpr (MOM) {
-                        buf_store<VW>(ga[q], rs_ga, (lane + q * 64) * VW * 4);
-                        buf_store<VW>(ha[q], rs_ha, (lane + q * 64) * VW * 4);
-                    }
+                    if (!rmw_row) *reinterpret_cast<VT *>(tr_c + (lane + q * 64) * VW) = dc;
+                    *reinterpret_cast<VT *>(tr_g + (lane + q * 64) * VW) = dg;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                 for (int k = 0; k < NCH * VW; ++k) {
-                    const int e = lane + k * 64;          // element index; past D the buffer check drops it
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_c[e], rs_a, e * 4, 0, 0);
-                    if constexpr (!MOM) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_g[e], rs_ga, e * 4, 0, 0);
+                    const int e = lane + k * 64;          // element index; past the row the buffer check drops it
+                    if (!rmw_row) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_c[e], rs_a, e * 4, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(tr_g[e], rs_ga, e * 4, 0, 0);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
             // The bias takes AdaGrad steps WITHOUT a learning rate (Adagrad.java:88-89): one run alone
-            // already moves it most of the way, so concurrent hub runs must not add up.  The scalars are
+            // already moves it most of the way, so concurrent runs must not add up.  The scalars are
             // merged last-writer-wins (what the Java race does), written through (sc1) like every table.
             if constexpr (FAT) {
-                if (lane == 0 && cur_hot && !MOM) {        // rows went out as atomic deltas: the bias slot of each row is stored on its own
+                if (lane == 0 && !store_all) {             // the rows did not go out whole: the bias slot of each row is stored on its own
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ab), rs_a, D * 4, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gab), rs_ga, D * 4, 0, AUX_SC1);
+                    if (!MOM) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gab), rs_ga, D * 4, 0, AUX_SC1);
                 }
             } else if (lane == 0) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ab), make_rsrc(A_bias + cur_id, 4), 0, 0, AUX_SC1);
@@ -669,7 +707,8 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
                         }
                 }
                 cur_id = skey < 0 ? ~skey : skey;
-                cur_hot = res_is_ctx && (p.blocked ? p.hot_enabled != 0 : skey < 0);
+                // shared = other workers may hold this row too: hub columns (context side), pieces of a long focus row
+                cur_hot = p.blocked ? (res_is_ctx ? p.hot_enabled != 0 : cur_id == c_meta) : skey < 0;
                 rs_a = rsN_a; rs_ga = rsN_ga; rs_ha = rsN_ha;
                 cur_a32 = n_a32;
                 run_len = 0;
@@ -680,7 +719,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
                 decode(pos + 1);
                 if (n_oth != b_id) request_streamed(); else deferred = true;   // same streamed row twice in a row: re-read after the store
                 // a long hub run is cut every p.flush_every nonzeros: publish the delta, re-read what the other workers published
-                next_new = n_key != skey || (cur_hot && run_len + 1 >= p.flush_every);
+                next_new = n_key != skey || (cur_hot && run_len + 1 >= flush_lim);
                 if (next_new) request_resident();
             }
             // dot product
@@ -811,8 +850,9 @@ hogwild_fn pick_hogwild(int D, int opt, bool emb16, int *vw_out, int *nch_out) {
 struct ge_glove {
     ge_glove_cfg cfg{};
     int32_t rows = 0;                 // focus rows owned = row_end - row_begin
-    float *tab[GE_STATE_COUNT] = {};  // device tables
+    float *tab[GE_STATE_COUNT] = {};  // device tables (several may point into one allocation: see `owned`)
     int64_t tab_count[GE_STATE_COUNT] = {};
+    std::vector<void *> owned;        // every device allocation of the handle
     int32_t *dI = nullptr, *dJ = nullptr, *dperm = nullptr;
     float *dX = nullptr;
     double *dL = nullptr;             // Hogwild: log term per nonzero
@@ -831,21 +871,27 @@ struct ge_glove {
     int hw_blocks_per_cu = 4;
     int hw_blocks = 0;
     int hw_workers = 0;
-    bool blocked = false;             // Hogwild + DEVICE shuffle: chunked layout below
+    bool blocked = false;             // Hogwild + DEVICE shuffle: the layout of ge_layout.h
+    ge::BlockedLayout lay;            // its device arrays (bA, bB, L, W, border, cstart, cmeta)
     int64_t n_chunks = 0, n_hchunks = 0;
-    int32_t *dbA = nullptr, *dbB = nullptr, *dchunk_flush = nullptr;
     int flush_every = RUN_CHUNK;
     bool emb16 = false;               // focus/context stored as bf16 (tab[] pointers then address uint16 data)
-    bool fat = false;                 // fp32 Hogwild: row tables are [rows x (D+4)] with the bias at [D]; tab[*BIAS] are null
-    int32_t ds = 0;                   // row stride of the fp32 row tables in floats (D, or D + 4 when fat)
+    bool fat = false;                 // fp32 Hogwild: a row is D + 4 floats with its bias at [D]; tab[*BIAS] are null
+    int32_t rw = 0;                   // row width of the fp32 row tables in floats (D, or D + 4 when fat)
+    int32_t ds = 0;                   // row stride of the fp32 row tables in floats (rw, or a multiple when the tables interleave)
     float *hub32 = nullptr;           // bf16 build: fp32 master rows of the hub columns
     int32_t *dhub_index = nullptr;
     std::vector<int32_t> host_hub_index;
     int32_t n_hub = 0;
-    std::vector<int32_t> host_key;    // sort key per (re-ordered) position: what the kernel stages as `key`
-    std::vector<int32_t> host_border; // blocked layout: original nonzero per position (-1 = padding)
+    std::vector<int32_t> host_key;    // general order: sort key per nonzero (what the kernel stages as `key`)
     int32_t hot_cols = 0;
     int64_t hot_nnz = 0, hot_threshold = 0;
+
+    template <typename T> hipError_t alloc(T **out, size_t n) {
+        hipError_t e = hipMalloc((void **)out, sizeof(T) * std::max<size_t>(n, 1));
+        if (e == hipSuccess) owned.push_back((void *)*out);
+        return e;
+    }
 };
 
 namespace {
@@ -877,15 +923,16 @@ void fill_params(const ge_glove *h, GloveParams &p, int32_t iteration) {
     p.gsf -= off * h->ds;
     if (!h->fat) { p.fbias -= off; p.gsfb -= off; }
     if (p.m2f) { p.m2f -= off * h->ds; if (!h->fat) p.m2fb -= off; }
-    p.DS = h->ds;
-    p.I = h->dI; p.J = h->dJ; p.X = h->dX; p.perm = h->dperm; p.L = h->dL; p.W = h->dW;
+    p.DS = h->ds; p.RW = h->rw;
+    p.I = h->dI; p.J = h->dJ; p.X = h->dX; p.perm = h->dperm;
+    p.L = h->blocked ? h->lay.L : h->dL; p.W = h->blocked ? h->lay.W : h->dW;
     p.cost_out = h->dcost;
     p.queue = reinterpret_cast<unsigned long long *>(h->dcost + 1);
     p.xmax = h->cfg.xmax; p.N = h->cfg.nnz; p.D = h->cfg.dim;
     p.cost_kind = h->cfg.cost; p.lr = h->cfg.learning_rate;
     p.order_mode = h->cfg.shuffle == GE_SHUFFLE_JAVA ? ORDER_PERM
                  : h->cfg.shuffle == GE_SHUFFLE_DEVICE ? ORDER_BIJECTION : ORDER_IDENTITY;
-    p.bA = h->dbA; p.bB = h->dbB; p.chunk_flush = h->dchunk_flush; p.n_chunks = h->n_chunks; p.n_hchunks = h->n_hchunks;
+    p.bA = h->lay.bA; p.bB = h->lay.bB; p.cstart = h->lay.cstart; p.cmeta = h->lay.cmeta; p.n_chunks = h->n_chunks; p.n_hchunks = h->n_hchunks;
     p.blocked = h->blocked ? 1 : 0; p.hot_enabled = h->cfg.hot_columns != GE_HOT_NONE; p.flush_every = h->flush_every;
     const int64_t domain = h->blocked ? h->n_chunks : h->cfg.nnz;      // what the keyed bijection permutes
     uint32_t bits = 0;
@@ -941,13 +988,18 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     if (emb16 && (cfg->mode != GE_MODE_HOGWILD || cfg->shuffle != GE_SHUFFLE_DEVICE || cfg->opt != GE_OPT_ADAGRAD || cfg->dim % 4 != 0))
         return ge::fail(GE_ERR_ARG, "bf16 embeddings need mode=hogwild, shuffle=device, opt=adagrad and dim %% 4 == 0 (the reference path is fp32)");
     if (cfg->hot_columns < GE_HOT_AUTO || cfg->hot_columns > GE_HOT_ALL) return ge::fail(GE_ERR_ARG, "invalid hot_columns %d", cfg->hot_columns);
+    if (cfg->hot_theta < 0 || cfg->stale_budget < 0 || cfg->flush_every < 0 || cfg->blocks_per_cu < 0 || (cfg->layout_flags & ~7) != 0)
+        return ge::fail(GE_ERR_ARG, "invalid tuning fields (hot_theta %g, stale_budget %g, flush_every %d, blocks_per_cu %d, layout_flags %d)",
+                        (double)cfg->hot_theta, (double)cfg->stale_budget, cfg->flush_every, cfg->blocks_per_cu, cfg->layout_flags);
     int32_t rb = cfg->row_begin, re = cfg->row_end;
     if (rb == 0 && re == 0) re = cfg->vocab_size;
     if (rb < 0 || re > cfg->vocab_size || rb >= re) return ge::fail(GE_ERR_ARG, "invalid row range [%d,%d)", rb, re);
-    for (int64_t k = 0; k < cfg->nnz; ++k) {
-        if (I[k] < rb || I[k] >= re) return ge::fail(GE_ERR_ARG, "I[%lld]=%d outside owned rows [%d,%d)", (long long)k, I[k], rb, re);
-        if (J[k] < 0 || J[k] >= cfg->vocab_size) return ge::fail(GE_ERR_ARG, "J[%lld]=%d outside [0,%d)", (long long)k, J[k], cfg->vocab_size);
-    }
+    const bool will_block = cfg->mode == GE_MODE_HOGWILD && cfg->shuffle == GE_SHUFFLE_DEVICE;   // blocked layout, built (and range-checked) on the device
+    if (!will_block)
+        for (int64_t k = 0; k < cfg->nnz; ++k) {
+            if (I[k] < rb || I[k] >= re) return ge::fail(GE_ERR_ARG, "I[%lld]=%d outside owned rows [%d,%d)", (long long)k, I[k], rb, re);
+            if (J[k] < 0 || J[k] >= cfg->vocab_size) return ge::fail(GE_ERR_ARG, "J[%lld]=%d outside [0,%d)", (long long)k, J[k], cfg->vocab_size);
+        }
     ge_status st = ge::select_device(cfg->device);
     if (st != GE_OK) return st;
 
@@ -956,41 +1008,57 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     h->cfg = *cfg;
     h->emb16 = emb16;
     h->fat = cfg->mode == GE_MODE_HOGWILD && !emb16 && fat_rows_fit(cfg->dim);
-    h->ds = h->fat ? cfg->dim + 4 : cfg->dim;
     h->cfg.row_begin = rb; h->cfg.row_end = re;
     h->rows = re - rb;
     h->stream = (hipStream_t)cfg->stream;
     const int32_t V = cfg->vocab_size, D = cfg->dim;
     const int64_t N = cfg->nnz;
+    const bool moments = cfg->opt != GE_OPT_ADAGRAD;      // Adam / AMSGrad keep M2* next to M1*
+    const bool interleave = cfg->mode == GE_MODE_HOGWILD && !emb16 && (cfg->layout_flags & GE_LAYOUT_INTERLEAVE) != 0;
+    h->rw = h->fat ? D + 4 : D;
+    h->ds = h->rw * (interleave ? (moments ? 3 : 2) : 1);
 
+    // every failure below frees what the handle owns so far (ge_glove_destroy walks h->owned)
 #define GE_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ge_status _s = ge::fail(_e == hipErrorOutOfMemory ? GE_ERR_OOM : GE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); ge_glove_destroy(h); return _s; } } while (0)
 
     hipDeviceProp_t prop;
     GE_TRY(hipGetDeviceProperties(&prop, cfg->device));
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-    const bool moments = cfg->opt != GE_OPT_ADAGRAD;      // Adam / AMSGrad keep M2* next to M1*
+    // ---- tables, allocated once, in their final layout ------------------------------------------------------------
+    // fp32 row tables: `rw` floats per row (fat rows carry the bias at [D]); with GE_LAYOUT_INTERLEAVE a side is ONE
+    // allocation of records [row | accumulator row (| second moment row)], stride ds = 2 or 3 rw.  bf16 rows: dense
+    // [rows x D] bf16 tables, fp32 accumulators, separate bias vectors.
     const int64_t counts[GE_STATE_COUNT] = {
         (int64_t)h->rows * D, (int64_t)V * D, h->rows, V, (int64_t)h->rows * D, (int64_t)V * D, h->rows, V,
         moments ? (int64_t)h->rows * D : 0, moments ? (int64_t)V * D : 0, moments ? h->rows : 0, moments ? V : 0};
-    for (int t = 0; t < GE_STATE_COUNT; ++t) {
-        h->tab_count[t] = counts[t];
-        if (counts[t] > 0) GE_TRY(hipMalloc((void **)&h->tab[t], sizeof(float) * (size_t)counts[t]));
+    for (int t = 0; t < GE_STATE_COUNT; ++t) h->tab_count[t] = counts[t];
+    {
+        static const int ROWT[2][3] = {{GE_STATE_FOCUS, GE_STATE_GSQ_FOCUS, GE_STATE_M2_FOCUS}, {GE_STATE_CONTEXT, GE_STATE_GSQ_CONTEXT, GE_STATE_M2_CONTEXT}};
+        static const int BIAST[2][3] = {{GE_STATE_FBIAS, GE_STATE_GSQ_FBIAS, GE_STATE_M2_FBIAS}, {GE_STATE_CBIAS, GE_STATE_GSQ_CBIAS, GE_STATE_M2_CBIAS}};
+        const int n_aux = moments ? 3 : 2;
+        for (int side = 0; side < 2; ++side) {
+            const size_t nr = side == 0 ? (size_t)h->rows : (size_t)V;
+            if (interleave) {
+                float *blk = nullptr;
+                GE_TRY(h->alloc(&blk, nr * (size_t)h->ds));
+                for (int a = 0; a < n_aux; ++a) h->tab[ROWT[side][a]] = blk + (size_t)a * h->rw;
+            } else {
+                for (int a = 0; a < n_aux; ++a) {
+                    if (a == 0 && emb16) { uint16_t *t16 = nullptr; GE_TRY(h->alloc(&t16, nr * (size_t)D)); h->tab[ROWT[side][0]] = reinterpret_cast<float *>(t16); }
+                    else GE_TRY(h->alloc(&h->tab[ROWT[side][a]], nr * (size_t)h->ds));
+                }
+            }
+            if (!h->fat) for (int a = 0; a < n_aux; ++a) GE_TRY(h->alloc(&h->tab[BIAST[side][a]], nr));
+        }
     }
     const size_t nn = (size_t)std::max<int64_t>(N, 1);
-    const bool will_block = cfg->mode == GE_MODE_HOGWILD && cfg->shuffle == GE_SHUFFLE_DEVICE;   // blocked layout: bA/bB replace I/J
-    if (!will_block) {
-        GE_TRY(hipMalloc((void **)&h->dI, sizeof(int32_t) * nn));
-        GE_TRY(hipMalloc((void **)&h->dJ, sizeof(int32_t) * nn));
-    }
-    GE_TRY(hipMalloc((void **)&h->dX, sizeof(float) * nn));
-    GE_TRY(hipMalloc((void **)&h->dcost, 2 * sizeof(double)));
-    GE_TRY(hipMalloc((void **)&h->djob, sizeof(float) * (size_t)cfg->threads));
-    h->host_key.clear(); h->host_border.clear();
-    std::vector<float> bX;            // blocked order: X per re-ordered position
+    GE_TRY(h->alloc(&h->dcost, 2));
+    GE_TRY(h->alloc(&h->djob, (size_t)cfg->threads));
+    GE_TRY(hipEventCreate(&h->ev0));
+    GE_TRY(hipEventCreate(&h->ev1));
+
     if (cfg->mode == GE_MODE_HOGWILD) {
-        if (const char *e = std::getenv("GE_GLOVE_BLOCKS_PER_CU")) h->hw_blocks_per_cu = std::max(1, std::atoi(e));
-        if (const char *e = std::getenv("GE_GLOVE_FLUSH_EVERY")) h->flush_every = std::max(1, std::atoi(e));
         h->hw_fn = pick_hogwild(D, cfg->opt, emb16, &h->hw_vw, &h->hw_nch);
         if (!h->hw_fn) { ge_glove_destroy(h); return ge::fail(GE_ERR_ARG, "dim %d not supported by the Hogwild kernel (max 1024 for dim%%4==0, 512 for other even dims, 256 for odd dims)", D); }
         // One wavefront = one sequential worker.  Never more workers than N/2048: a small matrix must
@@ -998,8 +1066,9 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
         const int groups_per_block = 4;
         const int64_t chunks = (N + RUN_CHUNK - 1) / RUN_CHUNK;
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(h->hw_fn), 256, 0) == hipSuccess && occ > 0)
-            h->hw_blocks_per_cu = std::getenv("GE_GLOVE_BLOCKS_PER_CU") ? h->hw_blocks_per_cu : occ;   // every worker resident: one wave of blocks
+        h->hw_blocks_per_cu = cfg->blocks_per_cu > 0 ? cfg->blocks_per_cu : 4;
+        if (cfg->blocks_per_cu == 0 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(h->hw_fn), 256, 0) == hipSuccess && occ > 0)
+            h->hw_blocks_per_cu = occ;                   // every worker resident: one wave of blocks
         int64_t blocks = std::min<int64_t>((chunks + 3) / 4, (int64_t)h->num_cus * h->hw_blocks_per_cu);
         blocks = std::min<int64_t>(blocks, std::max<int64_t>(1, N / 2048 / groups_per_block));
         h->hw_blocks = (int)std::max<int64_t>(blocks, 1);
@@ -1011,184 +1080,106 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
             h->hw_blocks = (int)std::max<int64_t>(1, (int64_t)h->hw_blocks - (-(int64_t)cfg->workers + 3) / 4);   // running beside (collectives)
             h->hw_workers = h->hw_blocks * 4;
         }
-        // ---- hub columns --------------------------------------------------------------------------
-        std::vector<int32_t> cnt((size_t)V, 0);
-        std::vector<uint8_t> hotcol((size_t)V, 0);
-        if (N > 0 && cfg->hot_columns != GE_HOT_NONE) {
-            double theta = 0.25;
-            if (const char *e = std::getenv("GE_GLOVE_HOT_THETA")) theta = std::atof(e);
-            const int64_t inflight = h->hw_workers;
-            const int64_t thr = cfg->hot_columns == GE_HOT_ALL ? 0
-                              : std::max<int64_t>(2, (int64_t)std::ceil(theta * (double)N / (double)inflight));
-            for (int64_t k = 0; k < N; ++k) ++cnt[(size_t)J[k]];
-            for (int32_t v = 0; v < V; ++v)
-                if (cnt[(size_t)v] >= thr && cnt[(size_t)v] > 0) { hotcol[(size_t)v] = 1; ++h->hot_cols; h->hot_nnz += cnt[(size_t)v]; }
-            h->hot_threshold = thr;
-        }
-        if (emb16) {
-            h->host_hub_index.assign((size_t)V, -1);
-            for (int32_t v = 0; v < V; ++v) if (hotcol[(size_t)v]) h->host_hub_index[(size_t)v] = h->n_hub++;
-        }
-        // Concurrent runs on one hub column add their deltas; each delta is stale by the length of the run.
-        // Summing K concurrent runs of m updates behaves like one step K*m times too long, and diverges
-        // once K*m*(lr*w*|row|^2) passes ~1 (measured: K*m = 39k diverges, 10k is stable at the bench
-        // scale).  A hub run is therefore cut -- delta published, row re-read -- every m_j updates with
-        // K_j * m_j <= stale_budget, K_j = expected workers inside column j = count_j * workers / N.
-        double stale_budget = 2000.0;
-        if (const char *e = std::getenv("GE_GLOVE_STALE_BUDGET")) stale_budget = std::max(1.0, std::atof(e));
-        auto flush_limit = [&](int32_t col) -> int32_t {
-            const double K = std::max(1.0, (double)cnt[(size_t)col] * (double)h->hw_workers / (double)std::max<int64_t>(N, 1));
-            const double m = std::floor(stale_budget / K);
-            return (int32_t)std::min<double>(RUN_CHUNK, std::max<double>(4.0, m));
-        };
-        if (!std::getenv("GE_GLOVE_FLUSH_EVERY")) {
-            int32_t m_min = RUN_CHUNK;
-            for (int32_t v = 0; v < V; ++v) if (hotcol[(size_t)v]) m_min = std::min(m_min, flush_limit(v));
-            h->flush_every = m_min;
-        }
+        const double theta = cfg->hot_theta > 0 ? (double)cfg->hot_theta : 0.25;
+        const double stale_budget = cfg->stale_budget > 0 ? (double)cfg->stale_budget : 2000.0;
         h->blocked = cfg->shuffle == GE_SHUFFLE_DEVICE;
-        if (!h->blocked) {
-            // general order (Java permutation / matrix order): hub columns are keyed ~j
+        if (h->blocked) {
+            ge::LayoutRequest rq{};
+            rq.V = V; rq.row_begin = rb; rq.row_end = re; rq.N = N; rq.cost = cfg->cost; rq.xmax = cfg->xmax;
+            rq.hot_columns = cfg->hot_columns; rq.hot_theta = theta; rq.stale_budget = stale_budget; rq.flush_every = cfg->flush_every;
+            rq.workers = h->hw_workers;
+            rq.shared_rows = (cfg->layout_flags & GE_LAYOUT_PLAIN_LONG_ROWS) ? 0 : 1;
+            rq.pack_rows = (cfg->layout_flags & GE_LAYOUT_FIXED_CUTS) ? 0 : 1;
+            rq.want_hub_index = emb16;
+            st = ge::build_blocked_layout(rq, I, J, X, h->stream, &h->lay);
+            if (st != GE_OK) { ge_glove_destroy(h); return st; }
+            h->n_chunks = h->lay.n_chunks; h->n_hchunks = h->lay.n_hchunks;
+            h->hot_cols = h->lay.hot_cols; h->hot_nnz = h->lay.hot_nnz; h->hot_threshold = h->lay.hot_threshold;
+            h->flush_every = h->lay.flush_min;
+            if (emb16) { h->host_hub_index.swap(h->lay.hub_index); h->n_hub = h->lay.n_hub; }
+        } else {
+            // general order (Java permutation / matrix order): the resident side is always the context row, hub columns are keyed ~j
+            std::vector<int32_t> cnt((size_t)V, 0);
+            std::vector<uint8_t> hotcol((size_t)V, 0);
+            if (N > 0 && cfg->hot_columns != GE_HOT_NONE) {
+                const int64_t thr = cfg->hot_columns == GE_HOT_ALL ? 0
+                                  : std::max<int64_t>(2, (int64_t)std::ceil(theta * (double)N / (double)h->hw_workers));
+                for (int64_t k = 0; k < N; ++k) ++cnt[(size_t)J[k]];
+                for (int32_t v = 0; v < V; ++v)
+                    if (cnt[(size_t)v] >= thr && cnt[(size_t)v] > 0) { hotcol[(size_t)v] = 1; ++h->hot_cols; h->hot_nnz += cnt[(size_t)v]; }
+                h->hot_threshold = thr;
+            }
+            h->flush_every = cfg->flush_every > 0 ? std::min<int32_t>(cfg->flush_every, RUN_CHUNK) : RUN_CHUNK;
+            if (cfg->flush_every == 0)
+                for (int32_t v = 0; v < V; ++v) if (hotcol[(size_t)v]) {
+                    const double K = std::max(1.0, (double)cnt[(size_t)v] * (double)h->hw_workers / (double)std::max<int64_t>(N, 1));
+                    h->flush_every = std::min<int>(h->flush_every, (int)std::min<double>(RUN_CHUNK, std::max<double>(4.0, std::floor(stale_budget / K))));
+                }
             h->host_key.assign(J, J + N);
             for (int64_t k = 0; k < N; ++k) if (hotcol[(size_t)J[k]]) h->host_key[(size_t)k] = ~J[k];
             h->n_chunks = chunks; h->n_hchunks = 0;
-        } else {
-            // Blocked order.  H = nonzeros of the hub columns, column-major (stable counting sort by j);
-            // R = the rest in matrix order, i.e. row-major as BookmarkColoring emits it.  Both are padded to
-            // whole chunks of 128; a chunk is the unit the epoch order permutes.
-            const int64_t nH = h->hot_nnz, nR = N - nH;
-            const int64_t Hpad = (nH + RUN_CHUNK - 1) / RUN_CHUNK * RUN_CHUNK, Rpad = (nR + RUN_CHUNK - 1) / RUN_CHUNK * RUN_CHUNK;
-            const size_t tot = (size_t)(Hpad + Rpad);
-            h->host_key.assign(tot, KEY_PAD);          // resident row id per position
-            h->host_border.assign(tot, -1);            // original nonzero per position
-            std::vector<int32_t> bB(tot, 0);
-            bX.assign(tot, 0.5f);
-            std::vector<int64_t> start((size_t)V + 1, 0);
-            for (int32_t v = 0; v < V; ++v) start[(size_t)v + 1] = start[(size_t)v] + (hotcol[(size_t)v] ? cnt[(size_t)v] : 0);
-            int64_t r = Hpad;
-            for (int64_t k = 0; k < N; ++k) {
-                const int32_t j = J[k];
-                size_t pos;
-                if (hotcol[(size_t)j]) { pos = (size_t)start[(size_t)j]++; h->host_key[pos] = j; bB[pos] = I[k]; }
-                else { pos = (size_t)r++; h->host_key[pos] = I[k]; bB[pos] = j; }
-                h->host_border[pos] = (int32_t)k; bX[pos] = X[k];
-            }
-            h->n_chunks = (int64_t)tot / RUN_CHUNK; h->n_hchunks = Hpad / RUN_CHUNK;
-            std::vector<int32_t> cf((size_t)std::max<int64_t>(h->n_hchunks, 1), RUN_CHUNK);
-            for (int64_t c = 0; c < h->n_hchunks; ++c) {
-                int32_t m = RUN_CHUNK;
-                for (int64_t k = c * RUN_CHUNK; k < (c + 1) * RUN_CHUNK; ++k)
-                    if (h->host_key[(size_t)k] != KEY_PAD) m = std::min(m, std::getenv("GE_GLOVE_FLUSH_EVERY") ? h->flush_every : flush_limit(h->host_key[(size_t)k]));
-                cf[(size_t)c] = m;
-            }
-            GE_TRY(hipMalloc((void **)&h->dchunk_flush, sizeof(int32_t) * cf.size()));
-            GE_TRY(hipMemcpy(h->dchunk_flush, cf.data(), sizeof(int32_t) * cf.size(), hipMemcpyHostToDevice));
-            GE_TRY(hipMalloc((void **)&h->dbA, sizeof(int32_t) * std::max<size_t>(tot, 1)));
-            GE_TRY(hipMalloc((void **)&h->dbB, sizeof(int32_t) * std::max<size_t>(tot, 1)));
-            if (tot) {
-                GE_TRY(hipMemcpy(h->dbA, h->host_key.data(), sizeof(int32_t) * tot, hipMemcpyHostToDevice));
-                GE_TRY(hipMemcpy(h->dbB, bB.data(), sizeof(int32_t) * tot, hipMemcpyHostToDevice));
-            }
         }
     } else if ((size_t)D * sizeof(float) > 64 * 1024) {
         ge_glove_destroy(h);
         return ge::fail(GE_ERR_ARG, "dim %d too large for deterministic mode", D);
     }
-    if (N > 0) {
-        const bool blocked = cfg->mode == GE_MODE_HOGWILD && h->blocked;
-        const size_t nx = blocked ? bX.size() : (size_t)N;
-        if (blocked && nx > nn) { (void)hipFree(h->dX); h->dX = nullptr; GE_TRY(hipMalloc((void **)&h->dX, sizeof(float) * nx)); }
-        if (!blocked) {
+    if (!h->blocked) {
+        GE_TRY(h->alloc(&h->dI, nn)); GE_TRY(h->alloc(&h->dJ, nn)); GE_TRY(h->alloc(&h->dX, nn));
+        if (N > 0) {
             GE_TRY(hipMemcpyAsync(h->dI, I, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
             GE_TRY(hipMemcpyAsync(h->dJ, h->host_key.empty() ? J : h->host_key.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+            GE_TRY(hipMemcpyAsync(h->dX, X, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, h->stream));
+            if (cfg->mode == GE_MODE_HOGWILD) {
+                GE_TRY(h->alloc(&h->dL, nn)); GE_TRY(h->alloc(&h->dW, nn));
+                const int blocks = (int)std::min<int64_t>((N + 255) / 256, 8192);
+                hipLaunchKernelGGL(k_cost_terms, dim3(blocks), dim3(256), 0, h->stream, h->dX, N, cfg->cost, cfg->xmax, h->dL, h->dW);
+            }
+            GE_TRY(hipStreamSynchronize(h->stream));
         }
-        GE_TRY(hipMemcpyAsync(h->dX, blocked ? bX.data() : X, sizeof(float) * nx, hipMemcpyHostToDevice, h->stream));
-        if (cfg->mode == GE_MODE_HOGWILD) {
-            GE_TRY(hipMalloc((void **)&h->dL, sizeof(double) * nx));
-            GE_TRY(hipMalloc((void **)&h->dW, sizeof(float) * nx));
-            const int blocks = (int)std::min<int64_t>(((int64_t)nx + 255) / 256, 8192);
-            hipLaunchKernelGGL(k_cost_terms, dim3(blocks), dim3(256), 0, h->stream, h->dX, (int64_t)nx, cfg->cost, cfg->xmax, h->dL, h->dW);
-        }
-        GE_TRY(hipStreamSynchronize(h->stream));
     }
     if (cfg->shuffle == GE_SHUFFLE_JAVA) {
-        GE_TRY(hipMalloc((void **)&h->dperm, sizeof(int32_t) * nn));
+        GE_TRY(h->alloc(&h->dperm, nn));
         h->perm.resize((size_t)N);
         for (int64_t k = 0; k < N; ++k) h->perm[(size_t)k] = (int32_t)k;     // Permutation ctor
     }
-    GE_TRY(hipEventCreate(&h->ev0));
-    GE_TRY(hipEventCreate(&h->ev1));
 
-    // --- parameter init in the reference's draw order; context side covers all V rows, the
-    //     focus side only the owned rows (same values a single-GPU run would hold there).
+    // --- parameter init in the reference's draw order, straight into the final layout; the context side covers all V
+    //     rows, the focus side only the owned rows (same values a single-GPU run would hold there).
     const uint64_t s0 = ge::JavaRandom::scramble(cfg->seed);
+    if (emb16) {
+        GE_TRY(h->alloc(&h->dhub_index, (size_t)V));
+        GE_TRY(hipMemcpyAsync(h->dhub_index, h->host_hub_index.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice, h->stream));
+        GE_TRY(h->alloc(&h->hub32, (size_t)std::max<int64_t>((int64_t)h->n_hub * D, 1)));
+    }
     {
-        // k_init_java writes focus+context+both biases of a row; run it per side with scratch for the other side.
-        // Single-GPU (rows == V): one launch fills everything.
-        if (h->rows == V) {
-            hipLaunchKernelGGL(k_init_java, dim3((V + 127) / 128), dim3(128), 0, h->stream,
-                               h->tab[GE_STATE_FOCUS], h->tab[GE_STATE_CONTEXT], h->tab[GE_STATE_FBIAS], h->tab[GE_STATE_CBIAS],
-                               0, V, D, s0);
-        } else {
-            float *scr_tab = nullptr, *scr_b = nullptr;
-            GE_TRY(hipMalloc((void **)&scr_tab, sizeof(float) * (size_t)V * D));
-            GE_TRY(hipMalloc((void **)&scr_b, sizeof(float) * (size_t)V));
-            // context side: all rows (focus outputs go to scratch)
-            hipLaunchKernelGGL(k_init_java, dim3((V + 127) / 128), dim3(128), 0, h->stream,
-                               scr_tab, h->tab[GE_STATE_CONTEXT], scr_b, h->tab[GE_STATE_CBIAS], 0, V, D, s0);
-            // focus side: owned rows (context outputs go to scratch)
-            hipLaunchKernelGGL(k_init_java, dim3((h->rows + 127) / 128), dim3(128), 0, h->stream,
-                               h->tab[GE_STATE_FOCUS], scr_tab, h->tab[GE_STATE_FBIAS], scr_b, rb, h->rows, D, s0);
-            GE_TRY(hipStreamSynchronize(h->stream));
-            (void)hipFree(scr_tab); (void)hipFree(scr_b);
-        }
+        const int64_t stride = emb16 ? D : h->ds;
+        const int32_t bias_col = h->fat ? D : -1;
+        void *foc = h->tab[GE_STATE_FOCUS], *ctx = h->tab[GE_STATE_CONTEXT];
+        auto launch = [&](void *f, void *c, int32_t row0, int32_t nrows) {
+            const dim3 g((unsigned)((nrows + 127) / 128)), b(128);
+            if (emb16) hipLaunchKernelGGL(k_init_java<true>, g, b, 0, h->stream, f, c, h->tab[GE_STATE_FBIAS], h->tab[GE_STATE_CBIAS], rb,
+                                          row0, nrows, D, stride, bias_col, h->rw, s0, (const int32_t *)h->dhub_index, h->hub32);
+            else hipLaunchKernelGGL(k_init_java<false>, g, b, 0, h->stream, f, c, h->tab[GE_STATE_FBIAS], h->tab[GE_STATE_CBIAS], rb,
+                                    row0, nrows, D, stride, bias_col, h->rw, s0, (const int32_t *)nullptr, (float *)nullptr);
+        };
+        if (h->rows == V) launch(foc, ctx, 0, V);
+        else { launch(nullptr, ctx, 0, V); launch(foc, nullptr, rb, h->rows); }
         // Adagrad ctor: gradSq = 1 (Adagrad.java:27-33); Adam / AMSGrad ctors: every moment = 0 (new float[])
-        for (int t = GE_STATE_GSQ_FOCUS; t < GE_STATE_COUNT; ++t) {
+        const float v0 = moments ? 0.0f : 1.0f;
+        for (int t : {GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_CONTEXT, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT}) {
+            if (!h->tab[t]) continue;
+            const int64_t nr = h->tab_count[t] / D;
+            const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((nr * h->rw + 255) / 256, 8192));
+            hipLaunchKernelGGL(k_fill_rows, dim3(blocks), dim3(256), 0, h->stream, h->tab[t], nr, (int64_t)h->ds, h->fat ? D + 1 : D, h->rw, v0);
+        }
+        for (int t : {GE_STATE_GSQ_FBIAS, GE_STATE_GSQ_CBIAS, GE_STATE_M2_FBIAS, GE_STATE_M2_CBIAS}) {
+            if (!h->tab[t]) continue;
             const int64_t n = h->tab_count[t];
-            if (n <= 0) continue;
-            const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
-            hipLaunchKernelGGL(k_fill, dim3(std::max(blocks, 1)), dim3(256), 0, h->stream, h->tab[t], n, moments ? 0.0f : 1.0f);
+            hipLaunchKernelGGL(k_fill, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096))), dim3(256), 0, h->stream, h->tab[t], n, v0);
         }
     }
     GE_TRY(hipGetLastError());
     GE_TRY(hipStreamSynchronize(h->stream));
-    if (emb16) {
-        // fp32 master rows of the hub columns, then narrow both embedding tables to bf16 (round to nearest even)
-        GE_TRY(hipMalloc((void **)&h->dhub_index, sizeof(int32_t) * (size_t)V));
-        GE_TRY(hipMemcpy(h->dhub_index, h->host_hub_index.data(), sizeof(int32_t) * (size_t)V, hipMemcpyHostToDevice));
-        GE_TRY(hipMalloc((void **)&h->hub32, sizeof(float) * (size_t)std::max<int64_t>((int64_t)h->n_hub * D, 1)));
-        hipLaunchKernelGGL(k_hub_rows, dim3((unsigned)V), dim3(64), 0, h->stream, h->tab[GE_STATE_CONTEXT], h->hub32, h->dhub_index, V, D, 0);
-        for (int t : {GE_STATE_FOCUS, GE_STATE_CONTEXT}) {
-            uint16_t *n16 = nullptr;
-            const int64_t n = h->tab_count[t];
-            GE_TRY(hipMalloc((void **)&n16, sizeof(uint16_t) * (size_t)std::max<int64_t>(n, 1)));
-            hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, h->stream, h->tab[t], n16, n);
-            GE_TRY(hipStreamSynchronize(h->stream));
-            (void)hipFree(h->tab[t]);
-            h->tab[t] = reinterpret_cast<float *>(n16);
-        }
-        GE_TRY(hipGetLastError());
-    }
-    if (h->fat) {
-        // every fp32 row table becomes [rows x (D+4)]: row | bias | zeros; the separate bias vectors go away
-        static const int pairs[6][2] = {{GE_STATE_FOCUS, GE_STATE_FBIAS}, {GE_STATE_CONTEXT, GE_STATE_CBIAS},
-                                        {GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_FBIAS}, {GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_CBIAS},
-                                        {GE_STATE_M2_FOCUS, GE_STATE_M2_FBIAS}, {GE_STATE_M2_CONTEXT, GE_STATE_M2_CBIAS}};
-        for (const auto &pr : pairs) {
-            const int64_t nr = h->tab_count[pr[1]];
-            if (nr <= 0 || !h->tab[pr[0]]) continue;
-            float *fatp = nullptr;
-            GE_TRY(hipMalloc((void **)&fatp, sizeof(float) * (size_t)nr * (size_t)h->ds));
-            GE_TRY(hipMemsetAsync(fatp, 0, sizeof(float) * (size_t)nr * (size_t)h->ds, h->stream));
-            const unsigned gb = (unsigned)std::min<int64_t>((nr * D + 255) / 256, 16384);
-            hipLaunchKernelGGL(k_fat_scatter, dim3(gb), dim3(256), 0, h->stream, fatp, nr, h->ds, 0, D, h->tab[pr[0]]);
-            hipLaunchKernelGGL(k_fat_scatter, dim3((unsigned)std::min<int64_t>((nr + 255) / 256, 16384)), dim3(256), 0, h->stream, fatp, nr, h->ds, D, 1, h->tab[pr[1]]);
-            GE_TRY(hipGetLastError());
-            GE_TRY(hipStreamSynchronize(h->stream));
-            (void)hipFree(h->tab[pr[0]]); (void)hipFree(h->tab[pr[1]]);
-            h->tab[pr[0]] = fatp; h->tab[pr[1]] = nullptr;
-        }
-    }
     h->rng.s = ge::JavaRandom::jump(s0, (uint64_t)V * (uint64_t)(2 + 2 * D));
 
 #undef GE_TRY
@@ -1256,18 +1247,24 @@ static const int FAT_HOME[GE_STATE_COUNT] = {GE_STATE_FOCUS, GE_STATE_CONTEXT, G
                                              GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_CONTEXT,
                                              GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT};
 static bool is_bias_table(int which) { return FAT_HOME[which] != which; }
+// does the API view of table `which` differ from how the handle stores it?  (fat rows: every fp32 table; interleaved
+// records: the row tables; bf16: the two embedding tables)
+static bool stored_strided(const ge_glove *h, int which) {
+    if (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT)) return false;     // bf16: converted, not gathered
+    return is_bias_table(which) ? h->fat : h->ds != h->cfg.dim;
+}
 static ge_status materialize_f32(ge_glove *h, int which, float **out) {
     const int64_t n = h->tab_count[which];
     float *d = nullptr;
     GE_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)std::max<int64_t>(n, 1)));
-    if (h->fat) {
+    if (stored_strided(h, which)) {
         const bool bias = is_bias_table(which);
         const int32_t D = h->cfg.dim;
         const int64_t rows = bias ? n : n / D;
         hipLaunchKernelGGL(k_fat_gather, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 16384))), dim3(256), 0, h->stream,
                            h->tab[FAT_HOME[which]], rows, h->ds, bias ? D : 0, bias ? 1 : D, d);
         hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { (void)hipFree(d); return ge::fail(GE_ERR_HIP, "fat row gather failed: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipFree(d); return ge::fail(GE_ERR_HIP, "row gather failed: %s", hipGetErrorString(e)); }
         *out = d;
         return GE_OK;
     }
@@ -1294,7 +1291,7 @@ static ge_status extract_impl(ge_glove *h, void *out, bool f64) {
     GE_HIP(hipMalloc(&d, bytes));
     const int blocks = (int)std::min<int64_t>((n + 255) / 256, 8192);
     float *foc = h->tab[GE_STATE_FOCUS], *ctx = h->tab[GE_STATE_CONTEXT];
-    const bool temp = h->emb16 || h->fat;
+    const bool temp = h->emb16 || stored_strided(h, GE_STATE_FOCUS);
     if (temp) {
         foc = ctx = nullptr;
         ge_status s1 = materialize_f32(h, GE_STATE_FOCUS, &foc);
@@ -1319,7 +1316,7 @@ ge_status ge_glove_get_state(ge_glove *h, int32_t which, float *out, int64_t cou
     if (which < 0 || which >= GE_STATE_COUNT || !out) return ge::fail(GE_ERR_ARG, "invalid state id %d or null buffer", which);
     if (count != h->tab_count[which]) return ge::fail(GE_ERR_ARG, "state %d holds %lld floats, caller passed %lld", which, (long long)h->tab_count[which], (long long)count);
     if (h->tab_count[which] == 0) return GE_OK;
-    if (h->fat || (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT))) {
+    if (stored_strided(h, which) || (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT))) {
         float *d = nullptr;
         st = materialize_f32(h, which, &d);
         if (st != GE_OK) return st;
@@ -1340,7 +1337,7 @@ ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_
     if (which < 0 || which >= GE_STATE_COUNT || !in) return ge::fail(GE_ERR_ARG, "invalid state id %d or null buffer", which);
     if (count != h->tab_count[which]) return ge::fail(GE_ERR_ARG, "state %d holds %lld floats, caller passed %lld", which, (long long)h->tab_count[which], (long long)count);
     if (count == 0) return GE_OK;
-    if (h->fat) {
+    if (stored_strided(h, which)) {
         float *d = nullptr;
         GE_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)count));
         hipError_t e = hipMemcpyAsync(d, in, sizeof(float) * (size_t)count, hipMemcpyHostToDevice, h->stream);
@@ -1381,11 +1378,12 @@ ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *
     if (which < 0 || which >= GE_STATE_COUNT || !dptr) return ge::fail(GE_ERR_ARG, "invalid state id %d or null out", which);
     if (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT))
         return ge::fail(GE_ERR_STATE, "table %d is stored as bf16 (+ fp32 hub rows); use ge_glove_get_state/set_state", which);
-    if (h->fat) {
-        // fat rows: the row tables are [n x row_stride] with the bias at column dim; a bias "table" is that column.
-        // *count = floats of the whole fat table; ge_glove_table_layout gives rows / stride / dim.
+    if (stored_strided(h, which)) {
+        // fat rows: a row table is [n x row_stride] with the bias at column dim; a bias "table" is that column of its home
+        // table.  *count = floats from the returned pointer to the end of the last row ((n - 1) * row_stride + row width).
         *dptr = h->tab[FAT_HOME[which]];
-        if (count) *count = (is_bias_table(which) ? h->tab_count[which] : h->tab_count[which] / h->cfg.dim) * (int64_t)h->ds;
+        const int64_t nr = is_bias_table(which) ? h->tab_count[which] : h->tab_count[which] / h->cfg.dim;
+        if (count) *count = nr > 0 ? (nr - 1) * (int64_t)h->ds + h->rw : 0;
         return GE_OK;
     }
     *dptr = h->tab[which];
@@ -1421,6 +1419,17 @@ static ge_status ge_glove_epoch_order_impl(ge_glove *h, int32_t iteration, int32
     if (count != N) return ge::fail(GE_ERR_ARG, "the epoch visits %lld nonzeros", (long long)N);
     GloveParams p;
     fill_params(h, p, iteration);
+    std::vector<int32_t> key, border, cstart;        // blocked layout: copied back from the device (a testing aid, not a hot path)
+    if (h->blocked) {
+        ge_status st = check_handle(h);
+        if (st != GE_OK) return st;
+        key.resize((size_t)std::max<int64_t>(N, 1)); border.resize(key.size()); cstart.resize((size_t)h->n_chunks + 1);
+        if (N > 0) {
+            GE_HIP(hipMemcpy(key.data(), h->lay.bA, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+            GE_HIP(hipMemcpy(border.data(), h->lay.border, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+        }
+        GE_HIP(hipMemcpy(cstart.data(), h->lay.cstart, sizeof(int32_t) * cstart.size(), hipMemcpyDeviceToHost));
+    }
     std::vector<std::pair<int32_t, int32_t>> ent;      // (key, original nonzero) of one chunk, in staging order
     int64_t w = 0;
     for (int64_t t = 0; t < h->n_chunks; ++t) {
@@ -1428,8 +1437,7 @@ static ge_status ge_glove_epoch_order_impl(ge_glove *h, int32_t iteration, int32
         if (h->blocked) {
             uint32_t x = (uint32_t)t;
             do { x = bij_round(x, p); } while ((int64_t)x >= h->n_chunks);
-            for (int64_t k = (int64_t)x * RUN_CHUNK; k < ((int64_t)x + 1) * RUN_CHUNK; ++k)
-                if (h->host_key[(size_t)k] != KEY_PAD) ent.push_back({h->host_key[(size_t)k], h->host_border[(size_t)k]});
+            for (int64_t k = cstart[(size_t)x]; k < cstart[(size_t)x + 1]; ++k) ent.push_back({key[(size_t)k], border[(size_t)k]});
         } else {
             for (int64_t k = t * RUN_CHUNK; k < std::min<int64_t>((t + 1) * RUN_CHUNK, N); ++k) {
                 const int64_t idx = h->cfg.shuffle == GE_SHUFFLE_JAVA ? h->perm[(size_t)k] : k;
@@ -1463,26 +1471,24 @@ ge_status ge_glove_get_info(ge_glove *h, ge_glove_info *info) {
     info->blocks = h->cfg.mode == GE_MODE_HOGWILD ? h->hw_blocks : 1;
     info->groups_in_flight = h->cfg.mode == GE_MODE_HOGWILD ? h->hw_workers : 1;
     info->hot_columns = h->hot_cols; info->hot_nonzeros = h->hot_nnz; info->hot_threshold = h->hot_threshold;
+    info->chunks = h->n_chunks; info->hub_chunks = h->n_hchunks; info->long_rows = h->lay.long_rows; info->shared_chunks = h->lay.shared_chunks;
+    info->flush_min = h->flush_every; info->row_stride = h->ds;
+    if (h->blocked) {
+        // one row access = the bytes a wavefront's row instruction moves: the row width of the table it touches
+        const int64_t emb = h->emb16 ? 2ll * h->cfg.dim : 4ll * h->rw, acc = 4ll * h->rw;
+        const int64_t aux = h->cfg.opt == GE_OPT_ADAGRAD ? 1 : 2;                 // accumulator rows per side
+        const int64_t pair = 2 * (emb + aux * acc) + (h->fat ? 0 : 2 * 4 * (1 + aux));   // load + store of a row, its accumulator row(s) and, unless fat, its scalars
+        info->runs = h->lay.n_runs;
+        info->schedule_bytes = h->cfg.nnz * (20 + pair) + h->lay.n_runs * pair;
+    }
     return GE_OK;
 }
 
 void ge_glove_destroy(ge_glove *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
-    for (int t = 0; t < GE_STATE_COUNT; ++t) if (h->tab[t]) (void)hipFree(h->tab[t]);
-    if (h->dI) (void)hipFree(h->dI);
-    if (h->dJ) (void)hipFree(h->dJ);
-    if (h->dX) (void)hipFree(h->dX);
-    if (h->dperm) (void)hipFree(h->dperm);
-    if (h->dbA) (void)hipFree(h->dbA);
-    if (h->dbB) (void)hipFree(h->dbB);
-    if (h->hub32) (void)hipFree(h->hub32);
-    if (h->dhub_index) (void)hipFree(h->dhub_index);
-    if (h->dchunk_flush) (void)hipFree(h->dchunk_flush);
-    if (h->dL) (void)hipFree(h->dL);
-    if (h->dW) (void)hipFree(h->dW);
-    if (h->dcost) (void)hipFree(h->dcost);
-    if (h->djob) (void)hipFree(h->djob);
+    for (void *q : h->owned) (void)hipFree(q);
+    h->lay.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;

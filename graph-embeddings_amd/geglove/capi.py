@@ -18,6 +18,7 @@ GE_MODE_HOGWILD, GE_MODE_DETERMINISTIC = 0, 1
 GE_SHUFFLE_JAVA, GE_SHUFFLE_DEVICE, GE_SHUFFLE_NONE = 0, 1, 2
 GE_HOT_AUTO, GE_HOT_NONE, GE_HOT_ALL = 0, 1, 2
 GE_DTYPE_F32, GE_DTYPE_BF16 = 0, 1
+GE_LAYOUT_FIXED_CUTS, GE_LAYOUT_PLAIN_LONG_ROWS, GE_LAYOUT_INTERLEAVE = 1, 2, 4
 (GE_STATE_FOCUS, GE_STATE_CONTEXT, GE_STATE_FBIAS, GE_STATE_CBIAS, GE_STATE_GSQ_FOCUS,
  GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FBIAS, GE_STATE_GSQ_CBIAS, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT,
  GE_STATE_M2_FBIAS, GE_STATE_M2_CBIAS) = range(12)
@@ -31,7 +32,7 @@ SYMBOLS = (
     "ge_glove_extract_f64", "ge_glove_get_state", "ge_glove_set_state", "ge_glove_device_ptr",
     "ge_glove_epoch_order", "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
     "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn", "ge_exchange_turn_rows", "ge_exchange_turn_bf16", "ge_glove_context_layout",
-    "ge_sim_cfg_default", "ge_sim_cfg_size", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_device_count",
+    "ge_sim_cfg_default", "ge_sim_cfg_size", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_bca_cfg_size", "ge_device_count",
 )
 
 
@@ -41,13 +42,17 @@ class GloveCfg(C.Structure):
                 ("xmax", C.c_double), ("seed", C.c_int64), ("threads", C.c_int32),
                 ("mode", C.c_int32), ("shuffle", C.c_int32), ("device", C.c_int32),
                 ("stream", C.c_void_p), ("row_begin", C.c_int32), ("row_end", C.c_int32),
-                ("hot_columns", C.c_int32), ("workers", C.c_int32), ("emb_dtype", C.c_int32)]
+                ("hot_columns", C.c_int32), ("workers", C.c_int32), ("emb_dtype", C.c_int32),
+                ("hot_theta", C.c_float), ("stale_budget", C.c_float), ("flush_every", C.c_int32),
+                ("blocks_per_cu", C.c_int32), ("layout_flags", C.c_int32)]
 
 
 class GloveInfo(C.Structure):
     _fields_ = [("group_width", C.c_int32), ("vector_width", C.c_int32), ("chunks_per_lane", C.c_int32),
                 ("blocks", C.c_int32), ("groups_in_flight", C.c_int32), ("hot_columns", C.c_int32),
-                ("hot_nonzeros", C.c_int64), ("hot_threshold", C.c_int64)]
+                ("hot_nonzeros", C.c_int64), ("hot_threshold", C.c_int64), ("chunks", C.c_int64), ("hub_chunks", C.c_int64),
+                ("long_rows", C.c_int64), ("shared_chunks", C.c_int64), ("flush_min", C.c_int32), ("row_stride", C.c_int32),
+                ("runs", C.c_int64), ("schedule_bytes", C.c_int64)]
 
 
 class Csr(C.Structure):
@@ -58,7 +63,7 @@ class Csr(C.Structure):
 class BcaCfg(C.Structure):
     _fields_ = [("alpha", C.c_double), ("epsilon", C.c_double), ("directed", C.c_int32),
                 ("normalize", C.c_int32), ("device", C.c_int32), ("row_begin", C.c_int32),
-                ("row_end", C.c_int32)]
+                ("row_end", C.c_int32), ("table_slots", C.c_int64), ("pool_entries", C.c_int64)]
 
 
 class SimCfg(C.Structure):
@@ -146,6 +151,10 @@ def lib():
     L.ge_device_count.argtypes = []; L.ge_device_count.restype = C.c_int32
     L.ge_glove_cfg_size.argtypes = []; L.ge_glove_cfg_size.restype = C.c_int32
     L.ge_sim_cfg_size.argtypes = []; L.ge_sim_cfg_size.restype = C.c_int32
+    L.ge_bca_cfg_size.argtypes = []; L.ge_bca_cfg_size.restype = C.c_int32
+    if L.ge_bca_cfg_size() != C.sizeof(BcaCfg):
+        raise ImportError("libgeglove.so was built from another revision of include/geglove.h (ge_bca_cfg is %d bytes there, %d here): "
+                          "rebuild with `make -C graph-embeddings_amd/csrc`" % (L.ge_bca_cfg_size(), C.sizeof(BcaCfg)))
     if L.ge_sim_cfg_size() != C.sizeof(SimCfg):
         raise ImportError("libgeglove.so was built from another revision of include/geglove.h (ge_sim_cfg is %d bytes there, %d here): "
                           "rebuild with `make -C graph-embeddings_amd/csrc`" % (L.ge_sim_cfg_size(), C.sizeof(SimCfg)))

@@ -40,6 +40,9 @@ class Configuration:
     (`bca.reverse`, `bca.predicates`, `similarity[].predicate`), which the Java bean of this
     revision would reject.  New, optional keys live under `device:`:
       mode: hogwild|deterministic   shuffle: java|device|none   seed: <long>   id: <ordinal>
+      hot: auto|none|all   workers: <int>   dtype: f32|bf16
+      hot_theta, stale_budget, flush_every, blocks_per_cu (ge_glove_cfg; 0 / absent = library default)
+      layout: [fixed_cuts, plain_long_rows, interleave]   bca_table_slots, bca_pool_entries (ge_bca_cfg sizing)
     """
 
     def __init__(self, d=None):
@@ -155,7 +158,9 @@ class BookmarkColoring(CooMatrix):
         in_s = _csr_struct(V, graph["inn"], keep)
         norm = self._NORM[str(config.getNormalize()).lower()]
         rb, re = row_range if row_range else (0, 0)
-        cfg = capi.BcaCfg(config.getAlpha(), config.getEpsilon(), int(config.isDirected()), norm, device, rb, re)
+        dev = config.device or {}
+        cfg = capi.BcaCfg(config.getAlpha(), config.getEpsilon(), int(config.isDirected()), norm, device, rb, re,
+                          int(dev.get("bca_table_slots", 0)), int(dev.get("bca_pool_entries", 0)))
         h = C.c_void_p()
         capi.check(capi.lib().ge_bca_build(C.byref(out_s), C.byref(in_s), C.byref(cfg), C.byref(h)))
         try:
@@ -191,6 +196,8 @@ class Optimum:
 _MODES = {"hogwild": capi.GE_MODE_HOGWILD, "deterministic": capi.GE_MODE_DETERMINISTIC}
 _HOT = {"auto": capi.GE_HOT_AUTO, "none": capi.GE_HOT_NONE, "all": capi.GE_HOT_ALL}
 _SHUFFLES = {"java": capi.GE_SHUFFLE_JAVA, "device": capi.GE_SHUFFLE_DEVICE, "none": capi.GE_SHUFFLE_NONE}
+_LAYOUT = {"default": 0, "fixed_cuts": capi.GE_LAYOUT_FIXED_CUTS, "plain_long_rows": capi.GE_LAYOUT_PLAIN_LONG_ROWS,
+           "interleave": capi.GE_LAYOUT_INTERLEAVE}
 
 
 class Adagrad:
@@ -231,6 +238,11 @@ class Adagrad:
         cfg.hot_columns = _HOT[str(dev.get("hot", "auto")).lower()]
         cfg.workers = int(dev.get("workers", 0))
         cfg.emb_dtype = {"f32": capi.GE_DTYPE_F32, "bf16": capi.GE_DTYPE_BF16}[str(dev.get("dtype", "f32")).lower()]
+        cfg.hot_theta = float(dev.get("hot_theta", 0)); cfg.stale_budget = float(dev.get("stale_budget", 0))
+        cfg.flush_every = int(dev.get("flush_every", 0)); cfg.blocks_per_cu = int(dev.get("blocks_per_cu", 0))
+        lay = dev.get("layout") or []
+        for name in ([lay] if isinstance(lay, str) else lay):
+            cfg.layout_flags |= _LAYOUT[str(name).lower()]
         self._rows = (re - rb) if (rb, re) != (0, 0) else self.vocabSize
         self._cfg = cfg
         self._h = C.c_void_p()

@@ -232,7 +232,10 @@ struct Configuration {
                     std::vector<std::string> uri, blank, predicate, literal; } output;
     // new, optional block `device:` (never changes the meaning of a reference key)
     struct { std::string mode = "hogwild", shuffle = "device", hot = "auto", dtype = "f32", save_coo, load_coo;
-             long long seed = 0; bool has_seed = false; int id = 0; int workers = 0; } device;
+             long long seed = 0; bool has_seed = false; int id = 0; int workers = 0;
+             // Hogwild tuning (ge_glove_cfg: 0 = library default), layout: list of fixed_cuts | plain_long_rows | interleave
+             double hot_theta = 0, stale_budget = 0; int flush_every = 0, blocks_per_cu = 0, layout_flags = 0;
+             long long bca_table_slots = 0, bca_pool_entries = 0; } device;
     std::vector<std::string> ignored_keys;     // legacy keys of the shipped YAMLs that the bean does not know
 
     int getThreads() const {       // Configuration.java:71-73
@@ -319,6 +322,22 @@ struct Configuration {
                     else if (q.first == "dtype") c.device.dtype = q.second.scalar;
                     else if (q.first == "save_coo") c.device.save_coo = q.second.scalar;      // COO checkpoint
                     else if (q.first == "load_coo") c.device.load_coo = q.second.scalar;
+                    else if (q.first == "hot_theta") c.device.hot_theta = num(&q.second);
+                    else if (q.first == "stale_budget") c.device.stale_budget = num(&q.second);
+                    else if (q.first == "flush_every") c.device.flush_every = (int)num(&q.second);
+                    else if (q.first == "blocks_per_cu") c.device.blocks_per_cu = (int)num(&q.second);
+                    else if (q.first == "bca_table_slots") c.device.bca_table_slots = (long long)num(&q.second);
+                    else if (q.first == "bca_pool_entries") c.device.bca_pool_entries = (long long)num(&q.second);
+                    else if (q.first == "layout") {
+                        std::vector<std::string> names; bool present = false;
+                        if (q.second.kind == YNode::List) strlist(&q.second, present, names); else names.push_back(q.second.scalar);
+                        for (auto &nm : names) {
+                            if (nm == "fixed_cuts") c.device.layout_flags |= GE_LAYOUT_FIXED_CUTS;
+                            else if (nm == "plain_long_rows") c.device.layout_flags |= GE_LAYOUT_PLAIN_LONG_ROWS;
+                            else if (nm == "interleave") c.device.layout_flags |= GE_LAYOUT_INTERLEAVE;
+                            else if (!nm.empty() && nm != "default") throw std::invalid_argument("device.layout: unknown flag " + nm);
+                        }
+                    }
                 }
             } else c.ignored_keys.push_back(k);
         }
@@ -688,6 +707,7 @@ public:
         if (n == "none") cfg.normalize = GE_NORM_NONE; else if (n == "unity") cfg.normalize = GE_NORM_UNITY;
         else if (n == "counts") cfg.normalize = GE_NORM_COUNTS; else throw std::invalid_argument("No enum constant BCANormalization." + n);
         cfg.device = config.device.id;
+        cfg.table_slots = config.device.bca_table_slots; cfg.pool_entries = config.device.bca_pool_entries;
         ge_coo *h = nullptr;
         check(ge_bca_build(&out, &in, &cfg, &h));
         coo_.reset(h);
@@ -806,6 +826,9 @@ public:
         cfg.workers = config.device.workers;
         cfg.emb_dtype = config.device.dtype == "bf16" ? GE_DTYPE_BF16 : GE_DTYPE_F32;
         cfg.device = config.device.id;
+        cfg.hot_theta = (float)config.device.hot_theta; cfg.stale_budget = (float)config.device.stale_budget;
+        cfg.flush_every = config.device.flush_every; cfg.blocks_per_cu = config.device.blocks_per_cu;
+        cfg.layout_flags = config.device.layout_flags;
         ge_glove *h = nullptr;
         check(ge_glove_create(&cfg, m.dataI(), m.dataJ(), m.dataX(), &h));
         h_.reset(h);

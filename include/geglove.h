@@ -129,7 +129,26 @@ typedef struct {
                                workers = -k fills the device except for k wavefront slots, which stay free for
                                kernels running beside the epoch (the all-reduce of an overlapped exchange). */
     int32_t emb_dtype;      /* GE_DTYPE_*: storage of the focus/context rows                           */
+    /* HOGWILD tuning; 0 = the library default everywhere.  These change results (which columns publish by delta,
+     * how stale a hub run may get), so they live here and under the YAML `device:` block, not in the environment. */
+    float   hot_theta;      /* GE_HOT_AUTO: column j is a hub when count(j) * workers >= hot_theta * N.  Default 0.25 */
+    float   stale_budget;   /* a hub run is cut (delta published, row re-read) every m_j updates with
+                               K_j * m_j <= stale_budget, K_j = expected workers inside column j.  Default 2000
+                               (measured: 10 000 is stable at the bench scale, 39 000 diverges)                */
+    int32_t flush_every;    /* > 0: cut every hub run after this many updates instead (<= 128)              */
+    int32_t blocks_per_cu;  /* > 0: workgroups of 4 workers per CU; default = what the occupancy API reports */
+    int32_t layout_flags;   /* GE_LAYOUT_* below                                                            */
 } ge_glove_cfg;
+
+/* ge_glove_cfg.layout_flags (GE_SHUFFLE_DEVICE handles).  Default 0: focus rows are packed whole into chunks, so a row
+ * is resident in one worker per epoch; a row with more than 128 ordinary nonzeros is cut into pieces that publish the row
+ * by delta (float atomics; bf16 rows and Adam/AMSGrad: re-read + add + store), so no worker overwrites another one's run.
+ * FIXED_CUTS     round-1 layout: chunks cut every 128 positions whatever the rows (a row cut by a chunk boundary can be
+ *                resident in two workers; the later store discards the other worker's whole run) -- ablation / tests.
+ * PLAIN_LONG_ROWS  pieces of long rows store plainly (same hazard for those rows only) -- ablation / tests.
+ * INTERLEAVE     a side's row, accumulator row (and second-moment row) are one record of 2 (3) x row width floats:
+ *                the streamed loads / stores of one update hit one region per side instead of two (fp32 rows only). */
+enum { GE_LAYOUT_FIXED_CUTS = 1, GE_LAYOUT_PLAIN_LONG_ROWS = 2, GE_LAYOUT_INTERLEAVE = 4 };
 
 /* What the library decided for a handle (reporting / DESIGN.md numbers). */
 typedef struct {
@@ -141,6 +160,16 @@ typedef struct {
     int32_t hot_columns;      /* columns updated with atomics                              */
     int64_t hot_nonzeros;     /* nonzeros whose column is hot                              */
     int64_t hot_threshold;    /* count(j) >= this => hot                                   */
+    int64_t chunks;           /* GE_SHUFFLE_DEVICE: chunks per epoch (<= 128 nonzeros each) ...          */
+    int64_t hub_chunks;       /*   ... of which hub-column chunks                                         */
+    int64_t long_rows;        /*   focus rows cut into pieces (more than 128 ordinary nonzeros)           */
+    int64_t shared_chunks;    /*   chunks that are such a piece (they publish the row by delta)           */
+    int32_t flush_min;        /* smallest flush limit of a hub run                                        */
+    int32_t row_stride;       /* floats between rows of the fp32 row tables                               */
+    int64_t runs;             /*   runs per epoch: a run loads its resident row pair once and publishes it once */
+    int64_t schedule_bytes;   /* bytes one epoch of this schedule has to move (what bench.py's roofline.achieved divides by the
+                                 kernel time): per nonzero 20 B of (bA, bB, L, W) + the streamed row and its accumulator row(s)
+                                 loaded and stored; per run the resident row and its accumulator row(s) loaded and published */
 } ge_glove_info;
 
 
@@ -219,7 +248,11 @@ typedef struct {
     int32_t device;      /* HIP device ordinal */
     int32_t row_begin;   /* bookmarks [row_begin,row_end) only; 0,0 = all (multi-GPU sharding) */
     int32_t row_end;
+    int64_t table_slots; /* sizing only, results do not depend on it: slots of a wavefront's work table (0 = from V; it
+                            grows by itself on overflow) ...                                                       */
+    int64_t pool_entries;/*   ... and entries of the first row pool (0 = from a sample of 2048 bookmarks)            */
 } ge_bca_cfg;
+/* Diagnostics read from the environment (never results): GE_BCA_TIMING=1 prints the phases of ge_bca_build to stderr. */
 
 /* Runs one BCA job per bookmark (BCAJob.call, J/bca/util/BCAJob.java:31-36) on the device and
  * assembles the COO in ascending bookmark order with each row in java.util.HashMap iteration
@@ -340,6 +373,7 @@ const char *ge_version(void);
 /* sizeof(ge_glove_cfg) as the LIBRARY was compiled: a host built against another header revision must refuse to
  * run instead of letting ge_glove_cfg_default write past its struct. */
 int32_t ge_glove_cfg_size(void);
+int32_t ge_bca_cfg_size(void);
 /* Number of visible HIP devices that are gfx950; <0 on HIP error. Does not compute. */
 int32_t ge_device_count(void);
 

@@ -18,14 +18,14 @@ pytestmark = pytest.mark.gpu
 NORMS = {"none": O.NORM_NONE, "unity": O.NORM_UNITY, "counts": O.NORM_COUNTS}
 
 
-def _cfg(alpha=0.1, epsilon=1e-3, directed=True, normalize="none"):
-    c = make_config(8)
+def _cfg(alpha=0.1, epsilon=1e-3, directed=True, normalize="none", device=None):
+    c = make_config(8, **(device or {}))
     c.bca = {"alpha": alpha, "epsilon": epsilon, "directed": directed, "normalize": normalize}
     return c
 
 
-def _check(graph, alpha=0.1, epsilon=1e-3, directed=True, normalize="none"):
-    dev = geglove.BookmarkColoring(graph, _cfg(alpha, epsilon, directed, normalize))
+def _check(graph, alpha=0.1, epsilon=1e-3, directed=True, normalize="none", device=None):
+    dev = geglove.BookmarkColoring(graph, _cfg(alpha, epsilon, directed, normalize, device))
     ref = O.bca_build(graph["V"], graph["out"], graph["inn"], alpha, epsilon, directed, NORMS[normalize])
     assert dev.coOccurrenceCount() == ref["nnz"]
     np.testing.assert_array_equal(dev.row_ptr, ref["row_ptr"])
@@ -156,19 +156,17 @@ def test_row_range_shards_concatenate(gpu):
     assert max(a.max(), b.max()) == full.max()
 
 
-def test_table_growth_path(gpu, monkeypatch):
+def test_table_growth_path(gpu):
     """Force the smallest work table: the builder must grow it and still be exact."""
-    monkeypatch.setenv("GE_BCA_TABLE", "64")
     g = synth.dblp_like_graph(300, 500, 4)
-    _check(g)
+    _check(g, device={"bca_table_slots": 64})
 
 
-def test_row_pool_overflow_path(gpu, monkeypatch):
+def test_row_pool_overflow_path(gpu):
     """A row pool that is far too small: the rows that did not fit are re-run alone into a second, exact pool."""
-    monkeypatch.setenv("GE_BCA_POOL", "1000")
     g = synth.dblp_like_graph(300, 500, 4)
-    _check(g)
-    _check(g, normalize="unity")
+    _check(g, device={"bca_pool_entries": 1000})
+    _check(g, normalize="unity", device={"bca_pool_entries": 1000})
 
 
 def test_bad_arguments(gpu):

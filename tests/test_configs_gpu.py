@@ -1,0 +1,124 @@
+"""The BASELINE.json configurations at (or near) their full sizes, under -m gpu.
+
+C2  synthetic 100 k vertices / 10 M nonzeros / dim 100 fp32, library-default workers: cost trajectory against the
+    sequential oracle, tolerance stated per epoch.
+C3' DBLP-like graph (a stand-in: the DBLP data is not in the reference) through the device builder at 50 k vertices,
+    dim 200, the shipped YAML's pglove: the TRAINED VECTORS of the production (Hogwild, blocked order) path against the
+    sequential oracle's, through the pairwise-cosine matrix of a vertex sample, plus the final cost.
+Lost runs: no focus row is resident in two workers at once -- measured, and shown to be what the
+    round-1 layout (layout: fixed_cuts) loses.
+The oracle is single-threaded here; these are the slow tests of the suite (about a minute in all)."""
+import numpy as np
+import pytest
+
+import geglove
+from geglove import synth
+import oracle as O
+from helpers import make_config
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_full_size_cost_trajectory(gpu):
+    """BASELINE C2.  Per-epoch mean cost, device (thousands of racing workers, blocked order) / sequential oracle
+    (Java order, same seed): within 10 % in the first two epochs (the blocked order alone shifts them), within 4 % after."""
+    V, D = 100_000, 100
+    I, J, X, xmax = synth.synthetic_coo_shard(V, (0, V), 12_100_000, seed=0xC0FFEE)     # the generator drops duplicate (i, j): 10.0 M remain
+    n = len(I)
+    assert 9_900_000 < n < 10_100_000
+    cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42)
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+    info = opt.info()
+    assert info["groups_in_flight"] >= 1024 and info["long_rows"] >= 0
+    dev = np.array([opt.epoch(it) / n for it in range(5)])
+    ora = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
+    ref = np.array([ora.epoch() for _ in range(5)])
+    print("C2 device/oracle per epoch:", np.round(dev / ref, 4).tolist(), "workers", info["groups_in_flight"])
+    assert np.all(np.isfinite(dev)) and dev[-1] < dev[0]
+    np.testing.assert_allclose(dev[:2], ref[:2], rtol=0.10)
+    np.testing.assert_allclose(dev[2:], ref[2:], rtol=0.04)
+
+
+def _cos_matrix(E):
+    n = E / np.maximum(np.linalg.norm(E, axis=1, keepdims=True), 1e-30)
+    return n @ n.T
+
+
+def test_c3_standin_trained_vectors_at_dim_200(gpu):
+    """DBLP-like graph, 50 k vertices -> ge_bca_build (bit-exact vs the oracle's builder) -> pglove, dim 200, Hogwild with
+    the library's worker count.  Vectors are compared through the pairwise-cosine matrix of 1500 sampled vertices
+    (invariant to what SGD leaves undetermined): correlation with the sequential Java-order oracle >= 0.995, final
+    cost within 3 %."""
+    g = synth.dblp_like_graph(10000, 15000, 40)
+    V, D, EP = g["V"], 200, 6
+    assert V >= 50_000
+    cfgb = make_config(D, "pglove")
+    bca = geglove.BookmarkColoring(g, cfgb)
+    ref = O.bca_build(V, g["out"], g["inn"], 0.1, 1e-3, True, O.NORM_NONE)
+    np.testing.assert_array_equal(bca.I, ref["I"]); np.testing.assert_array_equal(bca.J, ref["J"])
+    assert np.array_equal(bca.X.view(np.uint32), ref["X"].view(np.uint32)) and bca.max() == ref["max"]
+    I, J, X, xmax = bca.I, bca.J, bca.X, bca.max()
+    n = len(I)
+    cfg = make_config(D, "pglove", mode="hogwild", shuffle="device", seed=42)
+    opt = geglove.Adagrad(bca, cfg, cfg.costFunction())
+    info = opt.info()
+    for it in range(EP):
+        c_dev = opt.epoch(it) / n
+    E_dev = opt.extractResult().reshape(V, D)
+    ora = O.Glove(V, D, I, J, X, xmax, O.COST_PGLOVE, seed=42, threads=1)
+    for _ in range(EP):
+        c_ref = ora.epoch()
+    E_ref = ora.extract()
+    pick = np.random.default_rng(1).choice(V, 1500, replace=False)
+    iu = np.triu_indices(len(pick), 1)
+    rho = np.corrcoef(_cos_matrix(E_ref[pick])[iu], _cos_matrix(E_dev[pick])[iu])[0, 1]
+    print("C3 stand-in: %d vertices, %d nonzeros, %d workers, %d long rows; cost device %.6f oracle %.6f; cosine correlation %.5f"
+          % (V, n, info["groups_in_flight"], info["long_rows"], c_dev, c_ref, rho))
+    assert info["long_rows"] > 0                                      # rows of several hundred entries exist: the delta-publishing pieces ran
+    assert abs(c_dev / c_ref - 1) <= 0.03, (c_dev, c_ref)
+    assert rho >= 0.995, rho
+
+
+def _private_columns_matrix(rows, per_row, seed):
+    """`rows` focus rows of `per_row` nonzeros each, every nonzero on a column of its own: no context row is ever shared,
+    so what happens to focus row i depends on row i's own updates alone -- whatever the other workers do."""
+    rng = np.random.default_rng(seed)
+    n = rows * per_row
+    I = np.repeat(np.arange(rows, dtype=np.int32), per_row)
+    J = rng.permutation(n).astype(np.int32)
+    X = (10 ** rng.uniform(-3.5, -0.7, size=n)).astype(np.float32)
+    return n, I, J, X, 0.2                                             # vocabulary = n: one column per nonzero
+
+
+@pytest.mark.parametrize("per_row,dtype", [(200, "f32"), (90, "f32"), (200, "bf16"), (90, "bf16"), (700, "f32")])
+def test_no_focus_row_is_resident_in_two_workers(gpu, per_row, dtype):
+    """Known limit 1 of round 1: a focus row cut by a chunk boundary could be resident in two workers at once; the later
+    store discarded the other worker's WHOLE run (up to 128 updates and their gradSq increments).
+    Made exactly countable: 3000 rows, every nonzero on a private column, learning rate 0 and the bias accumulators at
+    1e30, so no parameter moves and the weighted cost wc of every nonzero is a constant.  gradSqFocus[i] then grows by
+    sum over row i's nonzeros of (wc * context)^2 -- the same number whatever the order and the concurrency, unless an
+    update's increment is discarded.
+      * default layout, 2048 racing workers: every row's growth equals the one-worker run's (fp32 summation order only;
+        90 per row = rows packed whole, bit for bit; 200 / 700 per row = 2 / 6 pieces that publish by delta).
+      * layout: fixed_cuts (round 1) on the same matrix loses whole runs -- which is what makes this test a test."""
+    rows, D = 3000, 64
+    V, I, J, X, xmax = _private_columns_matrix(rows, per_row, seed=per_row)
+
+    def run(layout, workers):
+        cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, hot="none", workers=workers, layout=layout, dtype=dtype,
+                          learning_rate=0.0)
+        opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+        opt.set_state("gsq_fbias", np.full(V, 1e30, np.float32)); opt.set_state("gsq_cbias", np.full(V, 1e30, np.float32))
+        f0 = opt.get_state("focus")
+        opt.epoch(0)
+        assert np.array_equal(opt.get_state("focus"), f0)               # nothing moves
+        return (opt.get_state("gsq_focus").reshape(V, D)[:rows].astype(np.float64) - 1).sum(1), opt.info()
+
+    g1, _ = run([], 1)
+    gp, info = run([], 2048)
+    go, _ = run(["fixed_cuts"], 2048)
+    print("per_row %d %s: gradSq growth / one worker: default layout %.6f .. %.6f (long rows %d, shared chunks %d); fixed cuts min %.3f, %d rows below 0.9"
+          % (per_row, dtype, (gp / g1).min(), (gp / g1).max(), info["long_rows"], info["shared_chunks"], (go / g1).min(), ((go / g1) < 0.9).sum()))
+    assert (info["long_rows"] == rows) == (per_row > 128)
+    np.testing.assert_allclose(gp, g1, rtol=1e-4)                       # no update's increment was discarded
+    assert ((go / g1) < 0.9).sum() > 20                                 # the round-1 layout does lose runs here

@@ -87,9 +87,10 @@ def test_two_ranks_share_one_gpu(gpu, exchange, V, N, D):
     ora = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
     ref = [ora.epoch() for _ in range(EPOCHS)]
     assert costs[-1] < costs[0]
-    # the overlapped form sees the other rank's first epoch only after its own second one: a bump there, then it closes
-    np.testing.assert_allclose(costs, ref, rtol=0.10 if exchange == "sync" else 0.15)
-    np.testing.assert_allclose(costs[-1], ref[-1], rtol=0.05)
+    # the overlapped form sees the other rank's first epoch only after its own second one: a bump there (on top of the
+    # shift the blocked order itself gives the first two epochs), then it closes
+    np.testing.assert_allclose(costs[:2], ref[:2], rtol=0.12 if exchange == "sync" else 0.20)
+    np.testing.assert_allclose(costs[2:], ref[2:], rtol=0.05)
 
 
 @pytest.mark.parametrize("n", [8 * 4096, 8 * 4096 + 5, 3, 1_000_003])

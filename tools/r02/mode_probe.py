@@ -35,6 +35,18 @@ for r in range(recreate):
     ms = []
     for it in range(epochs):
         opt.epoch(it); ms.append(round(opt.last_kernel_ms()[0], 3))
-    out["runs"].append({"create_s": round(tc, 2), "kernel_ms": ms})
+    run = {"create_s": round(tc, 2), "kernel_ms": ms}
+    if os.environ.get("GE_PROBE_CHASE"):
+        import ctypes as C
+        ch = C.CDLL(os.path.join(ROOT, "tools", "micro", "libchase.so"))
+        ch.chase.restype = C.c_double
+        ch.chase.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
+        for name in ("context", "focus", "gsq_context", "gsq_focus"):
+            ptr, n = opt.device_ptr(name)
+            run["ptr_" + name] = hex(ptr)
+            run["chase_idle_" + name] = round(ch.chase(ptr, V, 816, 20000, 1), 1)            # one wave: latency of a random row, TLB miss included
+            run["chase_small_" + name] = round(ch.chase(ptr, 20000, 816, 20000, 1), 1)      # 16 MB: translations cached
+            run["chase_load_" + name] = round(ch.chase(ptr, V, 816, 4000, 4096), 1)         # 4096 waves at once
+    out["runs"].append(run)
     opt.close()
 print(json.dumps(out), flush=True)
