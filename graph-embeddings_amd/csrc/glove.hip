@@ -1014,7 +1014,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     const int32_t V = cfg->vocab_size, D = cfg->dim;
     const int64_t N = cfg->nnz;
     const bool moments = cfg->opt != GE_OPT_ADAGRAD;      // Adam / AMSGrad keep M2* next to M1*
-    const bool interleave = cfg->mode == GE_MODE_HOGWILD && !emb16 && (cfg->layout_flags & GE_LAYOUT_INTERLEAVE) != 0;
+    const bool interleave = cfg->mode == GE_MODE_HOGWILD && !emb16 && (cfg->layout_flags & GE_LAYOUT_SEPARATE_TABLES) == 0;
     h->rw = h->fat ? D + 4 : D;
     h->ds = h->rw * (interleave ? (moments ? 3 : 2) : 1);
 
@@ -1026,7 +1026,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
     // ---- tables, allocated once, in their final layout ------------------------------------------------------------
-    // fp32 row tables: `rw` floats per row (fat rows carry the bias at [D]); with GE_LAYOUT_INTERLEAVE a side is ONE
+    // fp32 row tables: `rw` floats per row (fat rows carry the bias at [D]); unless GE_LAYOUT_SEPARATE_TABLES a side is ONE
     // allocation of records [row | accumulator row (| second moment row)], stride ds = 2 or 3 rw.  bf16 rows: dense
     // [rows x D] bf16 tables, fp32 accumulators, separate bias vectors.
     const int64_t counts[GE_STATE_COUNT] = {
@@ -1483,6 +1483,17 @@ ge_status ge_glove_get_info(ge_glove *h, ge_glove_info *info) {
     }
     return GE_OK;
 }
+
+}  // extern "C"
+namespace ge {
+// what sync.hip needs to know about a handle (struct ge_glove is private to this file)
+ge_status glove_sync_view(ge_glove *h, int32_t *opt, int32_t *mode, void **stream, int32_t *device) {
+    if (!h) return ge::fail(GE_ERR_ARG, "null ge_glove handle");
+    *opt = h->cfg.opt; *mode = h->cfg.mode; *stream = (void *)h->stream; *device = h->cfg.device;
+    return GE_OK;
+}
+}  // namespace ge
+extern "C" {
 
 void ge_glove_destroy(ge_glove *h) {
     if (!h) return;

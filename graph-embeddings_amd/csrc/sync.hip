@@ -1,0 +1,412 @@
+// sync.hip -- multi-GPU context exchange behind the C ABI (ge_sync_*, include/geglove.h).
+//
+// Rows shard: rank g owns a block of focus rows and their nonzeros; the CONTEXT side (context rows, cBias and their
+// AdaGrad accumulators) is replicated and reconciled by an all-reduce of the per-rank DELTAS.  The merge rule lives here
+// and nowhere else (chosen by simulating the ranks with the oracle):
+//   context rows, gradSqContext, gradSqCBias   new = old + sum_g delta_g            (steps carry the learning rate / squares add up)
+//   cBias                                      new = old + sum_g delta_g / #{g : delta_g != 0}
+//                                              (the reference updates biases WITHOUT a learning rate, Adagrad.java:88-89:
+//                                               one rank alone moves a hub bias most of the way, adding eight moves diverges)
+//   accumulators                               only every cfg.accum_every-th exchange
+// Every fp32 table keeps  base = the consensus c (start + every landed sum, the same bits on every rank)  and  own = this
+// rank's delta in flight; an exchange is
+//   take:  d = narrow(table - c - own in flight);  wire = own = d       (what bf16 drops stays in the table: error feedback)
+//   ---    all-reduce(SUM) of `wire` on the transport's stream, under the next epoch if the caller wishes (ge_sync_turn)
+//   land:  c += wire (mean rule: wire / count);  table = c + (table - c_old - own)
+// (bf16 rows go through ge_exchange_turn_bf16, whose base is consensus + own in flight.)
+// The table itself is never on the wire, so the epoch kernel may keep updating it while the all-reduce runs.
+// Transport: RCCL over xGMI (loaded at run time, so a single-GPU user needs no RCCL), or three callbacks of the host
+// (tests run two ranks on one GPU over gloo; the C++ CLI rehearses N ranks inside one process).
+// The wire / base buffers are DENSE [rows x cols] whatever the table's row stride (fat rows, interleaved records).
+#include "ge_common.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+// glove.hip
+extern "C" ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *count);
+namespace ge { ge_status glove_sync_view(ge_glove *h, int32_t *opt, int32_t *mode, void **stream, int32_t *device); }
+
+namespace {
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;       // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+// One exchange step over a logical [rows x cols] matrix stored in `table` with `t_stride` floats between rows; base, wire,
+// own (and cnt) are dense.  base = the CONSENSUS c (start + every landed sum: the same bits on every rank), own = this
+// rank's delta in flight:
+//   land:  c += m (m = wire, or wire / cnt under the mean rule);  resid = (table - c_old) - own;  table = c + resid
+//   take:  d = narrow(resid)  (resid = table - c: the moves not sent yet + what earlier narrowing dropped);  wire = own = d
+// After a synchronous exchange with an fp32 wire resid is exactly 0, so every rank's table IS c: bit-identical replicas.
+// W16: the wire is bf16.  MEAN: a take also writes cnt = (d != 0), all-reduced beside the wire.
+template <bool LAND, bool TAKE, bool W16, bool MEAN>
+__global__ __launch_bounds__(256) void k_sync_turn(float *__restrict__ table, int64_t t_stride, int32_t cols, int64_t n,
+                                                   float *__restrict__ base, void *__restrict__ wire_, void *__restrict__ own_,
+                                                   float *__restrict__ cnt) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {
+        const int64_t r = k / cols;
+        float *tp = table + r * t_stride + (k - r * cols);
+        float c = base[k];
+        float resid = *tp - c;
+        if (LAND) {
+            float w, o;
+            if (W16) { w = bf16_to_f32(reinterpret_cast<const uint16_t *>(wire_)[k]); o = bf16_to_f32(reinterpret_cast<const uint16_t *>(own_)[k]); }
+            else { w = reinterpret_cast<const float *>(wire_)[k]; o = reinterpret_cast<const float *>(own_)[k]; }
+            if (MEAN) w = w / fmaxf(cnt[k], 1.0f);
+            c += w;
+            resid -= o;                                                   // this rank's sent delta is inside w now
+            *tp = c + resid;
+            base[k] = c;
+        }
+        if (TAKE) {
+            if (W16) {
+                const uint32_t h = f32_to_bf16_rne(resid);
+                reinterpret_cast<uint16_t *>(wire_)[k] = (uint16_t)h; reinterpret_cast<uint16_t *>(own_)[k] = (uint16_t)h;
+                if (MEAN) cnt[k] = bf16_to_f32(h) != 0.0f ? 1.0f : 0.0f;
+            } else {
+                reinterpret_cast<float *>(wire_)[k] = resid; reinterpret_cast<float *>(own_)[k] = resid;
+                if (MEAN) cnt[k] = resid != 0.0f ? 1.0f : 0.0f;
+            }
+        }
+    }
+}
+
+// dense <-> strided copies (base initialisation, replicate)
+__global__ void k_gather(const float *table, int64_t t_stride, int32_t cols, int64_t n, float *dense) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) { const int64_t r = k / cols; dense[k] = table[r * t_stride + (k - r * cols)]; }
+}
+__global__ void k_scatter2(float *table, int64_t t_stride, int32_t cols, int64_t n, const float *dense, float *base) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) { const int64_t r = k / cols; const float v = dense[k]; table[r * t_stride + (k - r * cols)] = v; base[k] = v; }
+}
+// bf16 context rows: current values widened (hub rows from their fp32 masters)
+__global__ void k_bf16_values(const uint16_t *table, const float *hub_rows, const int32_t *hub_index, int32_t D, int64_t n, float *out) {
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {
+        const int64_t v = k / D; const int32_t h = hub_index[v];
+        out[k] = h >= 0 ? hub_rows[(int64_t)h * D + (k - v * D)] : bf16_to_f32(table[k]);
+    }
+}
+
+// ---- RCCL, resolved at run time --------------------------------------------------------------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl &rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    // a copy that is already in the process (PyTorch-ROCm bundles one) wins: one RCCL per process
+    static const char *names[] = {"librccl.so.1", "librccl.so"};
+    for (const char *n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    static const char *paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char *n : paths) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!r.lib) return r;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+    r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.Broadcast && r.GetErrorString;
+    return r;
+}
+#define GE_NCCL(expr)                                                                                              \
+    do { ncclResult_t _r = (expr); if (_r != ncclSuccess) return ge::fail(GE_ERR_HIP, "%s failed: %s", #expr, rccl().GetErrorString(_r)); } while (0)
+
+struct Entry {
+    const char *name = "";
+    float *table = nullptr; int64_t t_stride = 0; int32_t cols = 0; int64_t rows = 0, n = 0;
+    bool mean = false, lazy = false, w16 = false, bf16_rows = false;
+    float *base = nullptr, *cnt = nullptr; void *wire = nullptr, *own = nullptr;
+    bool in_flight = false;
+    void *ticket = nullptr, *ticket_cnt = nullptr;             // callback transport
+};
+
+unsigned grid_for(int64_t n, int cus) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, (int64_t)cus * 8)); }
+
+}  // namespace
+
+struct ge_sync {
+    ge_glove *h = nullptr;
+    ge_sync_cfg cfg{};
+    ge_transport tr{};              // callbacks (copied); tr.start == nullptr: RCCL
+    ncclComm_t comm = nullptr;
+    hipStream_t main = nullptr;     // the handle's stream: take / land kernels are ordered with its epochs
+    hipStream_t side = nullptr;     // RCCL's stream: the all-reduce runs beside the next epoch
+    hipEvent_t ev_taken = nullptr, ev_reduced = nullptr;
+    int device = 0, cus = 256;
+    std::vector<Entry> ent;
+    std::vector<void *> owned;
+    int64_t calls = 0;
+    uint32_t seed = 0x5EED;
+    ge_context_layout lay{};
+    template <typename T> hipError_t alloc(T **out, size_t n) {
+        hipError_t e = hipMalloc((void **)out, sizeof(T) * std::max<size_t>(n, 1));
+        if (e == hipSuccess) owned.push_back((void *)*out);
+        return e;
+    }
+};
+
+namespace {
+
+ge_status launch_turn(ge_sync *s, Entry &e, bool land, bool take) {
+    if (!land && !take) return GE_OK;
+    if (e.bf16_rows) {
+        s->seed = s->seed * 1664525u + 1013904223u;                    // same sequence on every rank, a new draw per turn
+        return ge_exchange_turn_bf16((uint16_t *)s->lay.table, s->lay.hub_rows, s->lay.hub_index, s->lay.vocab_size, s->lay.dim, e.base,
+                                     (uint16_t *)e.wire, (uint16_t *)e.own, land, take, s->seed ^ ((uint32_t)s->cfg.rank * 0x9E3779B1u), s->main);
+    }
+    const dim3 g(grid_for(e.n, s->cus)), b(256);
+#define GE_TURN(L, T)                                                                                                                        \
+    do {                                                                                                                                     \
+        if (e.mean) hipLaunchKernelGGL((k_sync_turn<L, T, false, true>), g, b, 0, s->main, e.table, e.t_stride, e.cols, e.n, e.base, e.wire, e.own, e.cnt); \
+        else if (e.w16) hipLaunchKernelGGL((k_sync_turn<L, T, true, false>), g, b, 0, s->main, e.table, e.t_stride, e.cols, e.n, e.base, e.wire, e.own, e.cnt); \
+        else hipLaunchKernelGGL((k_sync_turn<L, T, false, false>), g, b, 0, s->main, e.table, e.t_stride, e.cols, e.n, e.base, e.wire, e.own, e.cnt); \
+    } while (0)
+    if (land && take) GE_TURN(true, true); else if (land) GE_TURN(true, false); else GE_TURN(false, true);
+#undef GE_TURN
+    GE_HIP(hipGetLastError());
+    return GE_OK;
+}
+
+// starts the all-reduce of every entry taken in this call
+ge_status start_reduce(ge_sync *s, const std::vector<Entry *> &taken) {
+    if (taken.empty()) return GE_OK;
+    if (!s->tr.start) {
+        GE_HIP(hipEventRecord(s->ev_taken, s->main));
+        GE_HIP(hipStreamWaitEvent(s->side, s->ev_taken, 0));
+        for (Entry *e : taken) {
+            GE_NCCL(rccl().AllReduce(e->wire, e->wire, (size_t)e->n, e->w16 ? ncclBfloat16 : ncclFloat32, ncclSum, s->comm, s->side));
+            if (e->mean) GE_NCCL(rccl().AllReduce(e->cnt, e->cnt, (size_t)e->n, ncclFloat32, ncclSum, s->comm, s->side));
+        }
+        GE_HIP(hipEventRecord(s->ev_reduced, s->side));
+    } else {
+        GE_HIP(hipStreamSynchronize(s->main));                          // the host's collective reads the buffers
+        for (Entry *e : taken) {
+            ge_status st = s->tr.start(s->tr.user, e->wire, e->n, e->w16 ? GE_DTYPE_BF16 : GE_DTYPE_F32, &e->ticket);
+            if (st == GE_OK && e->mean) st = s->tr.start(s->tr.user, e->cnt, e->n, GE_DTYPE_F32, &e->ticket_cnt);
+            if (st != GE_OK) return ge::fail(st, "transport.start failed for %s", e->name);
+        }
+    }
+    for (Entry *e : taken) e->in_flight = true;
+    return GE_OK;
+}
+
+ge_status wait_reduce(ge_sync *s) {
+    bool any = false;
+    for (Entry &e : s->ent) any = any || e.in_flight;
+    if (!any) return GE_OK;
+    if (!s->tr.start) { GE_HIP(hipStreamWaitEvent(s->main, s->ev_reduced, 0)); return GE_OK; }
+    for (Entry &e : s->ent) {
+        if (!e.in_flight) continue;
+        ge_status st = s->tr.wait(s->tr.user, e.ticket);
+        if (st == GE_OK && e.mean) st = s->tr.wait(s->tr.user, e.ticket_cnt);
+        if (st != GE_OK) return ge::fail(st, "transport.wait failed for %s", e.name);
+    }
+    return GE_OK;
+}
+
+ge_status turn(ge_sync *s, bool land, bool take, bool everything) {
+    if (!s) return ge::fail(GE_ERR_ARG, "null ge_sync handle");
+    if (s->cfg.world == 1) return GE_OK;
+    GE_HIP(hipSetDevice(s->device));
+    bool due = false;
+    if (take) { ++s->calls; due = everything || s->calls % std::max(1, s->cfg.accum_every) == 0; }
+    if (take && !land) for (Entry &e : s->ent) if (e.in_flight) return ge::fail(GE_ERR_STATE, "ge_sync: finish the exchange in flight first");
+    if (land) { ge_status st = wait_reduce(s); if (st != GE_OK) return st; }
+    std::vector<Entry *> taken;
+    for (Entry &e : s->ent) {
+        const bool do_land = land && e.in_flight, do_take = take && (due || !e.lazy);
+        ge_status st = launch_turn(s, e, do_land, do_take);
+        if (st != GE_OK) return st;
+        if (do_land) e.in_flight = false;
+        if (do_take) taken.push_back(&e);
+    }
+    return start_reduce(s, taken);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ge_sync_cfg_size(void) { return (int32_t)sizeof(ge_sync_cfg); }
+
+ge_status ge_rccl_unique_id(void *id128) {
+    if (!id128) return ge::fail(GE_ERR_ARG, "null id buffer");
+    if (!rccl().ok) return ge::fail(GE_ERR_HIP, "RCCL is not available (librccl.so.1 could not be loaded)");
+    ncclUniqueId id;
+    GE_NCCL(rccl().GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    std::memcpy(id128, &id, sizeof(id));
+    return GE_OK;
+}
+
+void ge_sync_destroy(ge_sync *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->main) (void)hipStreamSynchronize(s->main);
+    if (s->side) (void)hipStreamSynchronize(s->side);
+    if (s->comm && rccl().ok) (void)rccl().CommDestroy(s->comm);
+    for (void *q : s->owned) (void)hipFree(q);
+    if (s->ev_taken) (void)hipEventDestroy(s->ev_taken);
+    if (s->ev_reduced) (void)hipEventDestroy(s->ev_reduced);
+    if (s->side) (void)hipStreamDestroy(s->side);
+    delete s;
+}
+
+static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_sync **out) {
+    if (!out) return ge::fail(GE_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (!h || !cfg) return ge::fail(GE_ERR_ARG, "null argument");
+    if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return ge::fail(GE_ERR_ARG, "invalid world / rank %d / %d", cfg->world, cfg->rank);
+    if (cfg->wire != GE_DTYPE_F32 && cfg->wire != GE_DTYPE_BF16) return ge::fail(GE_ERR_ARG, "wire must be GE_DTYPE_F32 or GE_DTYPE_BF16");
+    if (cfg->accum_every < 0) return ge::fail(GE_ERR_ARG, "accum_every must be >= 0");
+    if (cfg->transport && (!cfg->transport->start || !cfg->transport->wait || !cfg->transport->broadcast)) return ge::fail(GE_ERR_ARG, "transport needs start, wait and broadcast");
+    int32_t opt = 0, mode = 0, device = 0; void *stream = nullptr;
+    ge_status st = ge::glove_sync_view(h, &opt, &mode, &stream, &device);
+    if (st != GE_OK) return st;
+    if (mode != GE_MODE_HOGWILD) return ge::fail(GE_ERR_STATE, "the context exchange is defined for GE_MODE_HOGWILD handles");
+    if (opt != GE_OPT_ADAGRAD) return ge::fail(GE_ERR_STATE, "the context exchange (which deltas add, which average) is defined for adagrad only");
+    ge_sync *s = new (std::nothrow) ge_sync();
+    if (!s) return ge::fail(GE_ERR_OOM, "host allocation failed");
+    s->h = h; s->cfg = *cfg; s->cfg.transport = nullptr; s->cfg.rccl_id = nullptr;
+    if (s->cfg.accum_every == 0) s->cfg.accum_every = 4;
+    if (cfg->transport) s->tr = *cfg->transport;
+    s->main = (hipStream_t)stream; s->device = device;
+#define GE_TRYS(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ge_status _s = ge::fail(_e == hipErrorOutOfMemory ? GE_ERR_OOM : GE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); ge_sync_destroy(s); return _s; } } while (0)
+    GE_TRYS(hipSetDevice(device));
+    GE_TRYS(hipDeviceGetAttribute(&s->cus, hipDeviceAttributeMultiprocessorCount, device));
+    st = ge_glove_context_layout(h, &s->lay);
+    if (st != GE_OK) { ge_sync_destroy(s); return st; }
+    const int64_t V = s->lay.vocab_size; const int32_t D = s->lay.dim;
+    const bool w16 = cfg->wire == GE_DTYPE_BF16;
+    void *p_cb = nullptr, *p_gcb = nullptr; int64_t cnt = 0;
+    if ((st = ge_glove_device_ptr(h, GE_STATE_CBIAS, &p_cb, &cnt)) != GE_OK || (st = ge_glove_device_ptr(h, GE_STATE_GSQ_CBIAS, &p_gcb, &cnt)) != GE_OK) { ge_sync_destroy(s); return st; }
+    const bool bias_in_row = s->lay.dtype == GE_DTYPE_F32 && p_cb == s->lay.table;     // fat rows: the bias is column [dim] of its row
+    auto add = [&](const char *name, float *table, int64_t stride, int32_t cols, bool mean, bool lazy, bool narrow) {
+        Entry e; e.name = name; e.table = table; e.t_stride = stride; e.cols = cols; e.rows = V; e.n = V * cols;
+        e.mean = mean; e.lazy = lazy; e.w16 = narrow && !mean;
+        s->ent.push_back(e);
+    };
+    if (s->lay.dtype == GE_DTYPE_BF16) {
+        add("context rows (bf16)", nullptr, D, D, false, false, true);
+        s->ent.back().bf16_rows = true;
+    } else add("context rows", (float *)s->lay.table, s->lay.row_stride, D, false, false, w16);
+    add("cBias", bias_in_row ? (float *)s->lay.table + D : (float *)p_cb, bias_in_row ? s->lay.row_stride : 1, 1, true, false, false);
+    add("gradSqContext", s->lay.accum, s->lay.dtype == GE_DTYPE_BF16 ? D : s->lay.row_stride, D, false, true, w16);
+    add("gradSqCBias", bias_in_row ? s->lay.accum + D : (float *)p_gcb, bias_in_row ? s->lay.row_stride : 1, 1, false, true, false);
+    if (cfg->world > 1) {
+        for (Entry &e : s->ent) {
+            GE_TRYS(s->alloc(&e.base, (size_t)e.n));
+            const size_t wb = e.w16 ? 2 : 4;
+            GE_TRYS(s->alloc((char **)&e.wire, (size_t)e.n * wb)); GE_TRYS(s->alloc((char **)&e.own, (size_t)e.n * wb));
+            if (e.mean) GE_TRYS(s->alloc(&e.cnt, (size_t)e.n));
+            // the base is the table NOW, before any local pass
+            if (e.bf16_rows) hipLaunchKernelGGL(k_bf16_values, dim3(grid_for(e.n, s->cus)), dim3(256), 0, s->main, (const uint16_t *)s->lay.table, s->lay.hub_rows,
+                                                s->lay.hub_index, D, e.n, e.base);
+            else hipLaunchKernelGGL(k_gather, dim3(grid_for(e.n, s->cus)), dim3(256), 0, s->main, e.table, e.t_stride, e.cols, e.n, e.base);
+        }
+        GE_TRYS(hipGetLastError());
+        GE_TRYS(hipStreamSynchronize(s->main));
+        if (!s->tr.start) {
+            if (!cfg->rccl_id) { ge_sync_destroy(s); return ge::fail(GE_ERR_ARG, "world > 1 needs a transport or an RCCL unique id (ge_rccl_unique_id on rank 0, handed to every rank)"); }
+            if (!rccl().ok) { ge_sync_destroy(s); return ge::fail(GE_ERR_HIP, "RCCL is not available (librccl.so.1 could not be loaded)"); }
+            GE_TRYS(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+            GE_TRYS(hipEventCreateWithFlags(&s->ev_taken, hipEventDisableTiming));
+            GE_TRYS(hipEventCreateWithFlags(&s->ev_reduced, hipEventDisableTiming));
+            ncclUniqueId id; std::memcpy(&id, cfg->rccl_id, sizeof(id));
+            ncclResult_t r = rccl().CommInitRank(&s->comm, cfg->world, id, cfg->rank);
+            if (r != ncclSuccess) { ge_status e2 = ge::fail(GE_ERR_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString(r)); s->comm = nullptr; ge_sync_destroy(s); return e2; }
+        }
+    }
+#undef GE_TRYS
+    *out = s;
+    return GE_OK;
+}
+ge_status ge_sync_create(ge_glove *h, const ge_sync_cfg *cfg, ge_sync **out) { GE_GUARD(ge_sync_create_impl(h, cfg, out)); }
+
+ge_status ge_sync_begin(ge_sync *s, int32_t everything) { GE_GUARD(turn(s, false, true, everything != 0)); }
+ge_status ge_sync_finish(ge_sync *s) { GE_GUARD(turn(s, true, false, false)); }
+ge_status ge_sync_turn(ge_sync *s) { GE_GUARD(turn(s, true, true, false)); }
+ge_status ge_sync_sync(ge_sync *s) {          // lands what an earlier turn left in flight, takes, lands: nothing is in flight afterwards
+    ge_status st = ge_sync_turn(s);
+    return st == GE_OK ? ge_sync_finish(s) : st;
+}
+
+static ge_status ge_sync_replicate_impl(ge_sync *s, int32_t src) {
+    if (!s) return ge::fail(GE_ERR_ARG, "null ge_sync handle");
+    if (s->cfg.world == 1) return GE_OK;
+    if (src < 0 || src >= s->cfg.world) return ge::fail(GE_ERR_ARG, "replicate: src %d outside [0,%d)", src, s->cfg.world);
+    ge_status st = turn(s, true, true, true);                            // land what is in flight, send everything not sent yet
+    if (st == GE_OK) st = turn(s, true, false, false);
+    if (st != GE_OK) return st;
+    // every rank takes rank src's replica: what still differs is the rounding of own deltas.  (bf16 rows live partly in
+    // per-rank fp32 master rows -- hub sets differ per rank -- and are left as landed, equal up to bf16 rounding.)
+    for (Entry &e : s->ent) {
+        if (e.bf16_rows) continue;
+        float *stage = (float *)e.wire;                                   // dense fp32 staging; a bf16 wire buffer is too small
+        float *tmp = nullptr;
+        if (e.w16) { GE_HIP(hipMalloc((void **)&tmp, sizeof(float) * (size_t)e.n)); stage = tmp; }
+        hipLaunchKernelGGL(k_gather, dim3(grid_for(e.n, s->cus)), dim3(256), 0, s->main, e.table, e.t_stride, e.cols, e.n, stage);
+        ge_status r = GE_OK;
+        if (!s->tr.start) {
+            hipError_t he = hipEventRecord(s->ev_taken, s->main);
+            if (he == hipSuccess) he = hipStreamWaitEvent(s->side, s->ev_taken, 0);
+            ncclResult_t nr = he == hipSuccess ? rccl().Broadcast(stage, stage, (size_t)e.n, ncclFloat32, src, s->comm, s->side) : ncclSuccess;
+            if (he == hipSuccess && nr == ncclSuccess) { he = hipEventRecord(s->ev_reduced, s->side); if (he == hipSuccess) he = hipStreamWaitEvent(s->main, s->ev_reduced, 0); }
+            if (he != hipSuccess || nr != ncclSuccess) r = ge::fail(GE_ERR_HIP, "replicate: broadcast of %s failed", e.name);
+        } else {
+            if (hipStreamSynchronize(s->main) != hipSuccess) r = ge::fail(GE_ERR_HIP, "replicate: stream synchronize failed");
+            else if ((r = s->tr.broadcast(s->tr.user, stage, e.n, GE_DTYPE_F32, src)) != GE_OK) r = ge::fail(r, "transport.broadcast failed for %s", e.name);
+        }
+        if (r == GE_OK) hipLaunchKernelGGL(k_scatter2, dim3(grid_for(e.n, s->cus)), dim3(256), 0, s->main, e.table, e.t_stride, e.cols, e.n, stage, e.base);
+        hipError_t he = hipStreamSynchronize(s->main);
+        if (tmp) (void)hipFree(tmp);
+        if (r != GE_OK) return r;
+        if (he != hipSuccess) return ge::fail(GE_ERR_HIP, "replicate: %s", hipGetErrorString(he));
+    }
+    return GE_OK;
+}
+ge_status ge_sync_replicate(ge_sync *s, int32_t src) { GE_GUARD(ge_sync_replicate_impl(s, src)); }
+
+// Host scalars (the epoch's cost sums, a max over shards) over the same transport, so that a host without a
+// collective library of its own (the Java module) needs nothing else.  op: 0 = sum, 1 = max.  Blocking.
+static ge_status ge_sync_allreduce_f64_impl(ge_sync *s, double *values, int32_t n, int32_t op) {
+    if (!s || !values || n < 0) return ge::fail(GE_ERR_ARG, "invalid argument");
+    if (s->cfg.world == 1 || n == 0) return GE_OK;
+    if (s->tr.start) return ge::fail(GE_ERR_STATE, "ge_sync_allreduce_f64 runs over RCCL; a host that brought its own transport reduces its scalars there");
+    if (op != 0 && op != 1) return ge::fail(GE_ERR_ARG, "op must be 0 (sum) or 1 (max)");
+    GE_HIP(hipSetDevice(s->device));
+    double *d = nullptr;
+    GE_HIP(hipMalloc((void **)&d, sizeof(double) * (size_t)n));
+    hipError_t he = hipMemcpyAsync(d, values, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, s->side);
+    ncclResult_t nr = he == hipSuccess ? rccl().AllReduce(d, d, (size_t)n, ncclFloat64, op == 0 ? ncclSum : ncclMax, s->comm, s->side) : ncclSuccess;
+    if (he == hipSuccess && nr == ncclSuccess) he = hipMemcpyAsync(values, d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, s->side);
+    if (he == hipSuccess && nr == ncclSuccess) he = hipStreamSynchronize(s->side);
+    (void)hipFree(d);
+    if (nr != ncclSuccess) return ge::fail(GE_ERR_HIP, "ncclAllReduce failed: %s", rccl().GetErrorString(nr));
+    if (he != hipSuccess) return ge::fail(GE_ERR_HIP, "scalar all-reduce: %s", hipGetErrorString(he));
+    return GE_OK;
+}
+ge_status ge_sync_allreduce_f64(ge_sync *s, double *values, int32_t n, int32_t op) { GE_GUARD(ge_sync_allreduce_f64_impl(s, values, n, op)); }
+
+}  // extern "C"

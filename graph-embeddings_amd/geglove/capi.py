@@ -18,7 +18,7 @@ GE_MODE_HOGWILD, GE_MODE_DETERMINISTIC = 0, 1
 GE_SHUFFLE_JAVA, GE_SHUFFLE_DEVICE, GE_SHUFFLE_NONE = 0, 1, 2
 GE_HOT_AUTO, GE_HOT_NONE, GE_HOT_ALL = 0, 1, 2
 GE_DTYPE_F32, GE_DTYPE_BF16 = 0, 1
-GE_LAYOUT_FIXED_CUTS, GE_LAYOUT_PLAIN_LONG_ROWS, GE_LAYOUT_INTERLEAVE = 1, 2, 4
+GE_LAYOUT_FIXED_CUTS, GE_LAYOUT_PLAIN_LONG_ROWS, GE_LAYOUT_SEPARATE_TABLES = 1, 2, 4
 (GE_STATE_FOCUS, GE_STATE_CONTEXT, GE_STATE_FBIAS, GE_STATE_CBIAS, GE_STATE_GSQ_FOCUS,
  GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FBIAS, GE_STATE_GSQ_CBIAS, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT,
  GE_STATE_M2_FBIAS, GE_STATE_M2_CBIAS) = range(12)
@@ -31,7 +31,9 @@ SYMBOLS = (
     "ge_glove_cfg_default", "ge_glove_create", "ge_glove_epoch", "ge_glove_extract_f32",
     "ge_glove_extract_f64", "ge_glove_get_state", "ge_glove_set_state", "ge_glove_device_ptr",
     "ge_glove_epoch_order", "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
-    "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn", "ge_exchange_turn_rows", "ge_exchange_turn_bf16", "ge_glove_context_layout",
+    "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn_bf16", "ge_glove_context_layout",
+    "ge_rccl_unique_id", "ge_sync_cfg_size", "ge_sync_create", "ge_sync_begin", "ge_sync_finish", "ge_sync_turn", "ge_sync_sync",
+    "ge_sync_replicate", "ge_sync_allreduce_f64", "ge_sync_destroy",
     "ge_sim_cfg_default", "ge_sim_cfg_size", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_bca_cfg_size", "ge_device_count",
 )
 
@@ -79,6 +81,20 @@ class Strings(C.Structure):
 class ContextLayout(C.Structure):
     _fields_ = [("table", C.c_void_p), ("dtype", C.c_int32), ("hub_rows", C.c_void_p), ("hub_index", C.c_void_p),
                 ("n_hub", C.c_int32), ("vocab_size", C.c_int32), ("dim", C.c_int32), ("row_stride", C.c_int32), ("accum", C.c_void_p)]
+
+
+TRANSPORT_START = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p))
+TRANSPORT_WAIT = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p)
+TRANSPORT_BCAST = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)
+
+
+class Transport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("start", TRANSPORT_START), ("wait", TRANSPORT_WAIT), ("broadcast", TRANSPORT_BCAST)]
+
+
+class SyncCfg(C.Structure):
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("wire", C.c_int32), ("accum_every", C.c_int32),
+                ("transport", C.POINTER(Transport)), ("rccl_id", C.c_void_p)]
 
 
 class GeError(RuntimeError):
@@ -144,8 +160,18 @@ def lib():
     L.ge_sim_pairs_destroy.argtypes = [vp]; L.ge_sim_pairs_destroy.restype = None
     L.ge_glove_context_layout.argtypes = [vp, C.POINTER(ContextLayout)]
     L.ge_exchange_turn_bf16.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_uint32, vp]
-    L.ge_exchange_turn_rows.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
-    L.ge_exchange_turn.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_int32, vp]
+    L.ge_rccl_unique_id.argtypes = [vp]
+    L.ge_sync_cfg_size.argtypes = []; L.ge_sync_cfg_size.restype = C.c_int32
+    L.ge_sync_create.argtypes = [vp, C.POINTER(SyncCfg), C.POINTER(vp)]
+    L.ge_sync_begin.argtypes = [vp, C.c_int32]
+    for nm in ("ge_sync_finish", "ge_sync_turn", "ge_sync_sync"):
+        getattr(L, nm).argtypes = [vp]
+    L.ge_sync_replicate.argtypes = [vp, C.c_int32]
+    L.ge_sync_allreduce_f64.argtypes = [vp, f64p, C.c_int32, C.c_int32]
+    L.ge_sync_destroy.argtypes = [vp]; L.ge_sync_destroy.restype = None
+    if L.ge_sync_cfg_size() != C.sizeof(SyncCfg):
+        raise ImportError("libgeglove.so was built from another revision of include/geglove.h (ge_sync_cfg is %d bytes there, %d here)"
+                          % (L.ge_sync_cfg_size(), C.sizeof(SyncCfg)))
     L.ge_last_error.argtypes = []; L.ge_last_error.restype = C.c_char_p
     L.ge_version.argtypes = []; L.ge_version.restype = C.c_char_p
     L.ge_device_count.argtypes = []; L.ge_device_count.restype = C.c_int32

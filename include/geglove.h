@@ -146,9 +146,11 @@ typedef struct {
  * FIXED_CUTS     round-1 layout: chunks cut every 128 positions whatever the rows (a row cut by a chunk boundary can be
  *                resident in two workers; the later store discards the other worker's whole run) -- ablation / tests.
  * PLAIN_LONG_ROWS  pieces of long rows store plainly (same hazard for those rows only) -- ablation / tests.
- * INTERLEAVE     a side's row, accumulator row (and second-moment row) are one record of 2 (3) x row width floats:
- *                the streamed loads / stores of one update hit one region per side instead of two (fp32 rows only). */
-enum { GE_LAYOUT_FIXED_CUTS = 1, GE_LAYOUT_PLAIN_LONG_ROWS = 2, GE_LAYOUT_INTERLEAVE = 4 };
+ * SEPARATE_TABLES  round-1 storage: a table per kind.  Default (fp32 rows): a side's row and its accumulator row (and
+ *                second-moment row) are ONE record of 2 (3) x row width floats, so the loads / stores of one update touch
+ *                one region per side instead of two -- measured 7 % faster in alternation and free of the slow placements
+ *                separate tables fall into -- ablation / tests. */
+enum { GE_LAYOUT_FIXED_CUTS = 1, GE_LAYOUT_PLAIN_LONG_ROWS = 2, GE_LAYOUT_SEPARATE_TABLES = 4 };
 
 /* What the library decided for a handle (reporting / DESIGN.md numbers). */
 typedef struct {
@@ -201,9 +203,10 @@ ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_
 /* Raw device pointer of a table (for zero-copy wrapping by the host runtime, e.g. the
  * torch.distributed/RCCL all-reduce of the context factors). Valid until destroy.
  * GE_MODE_DETERMINISTIC handles: the table as the API shows it, *count floats.  GE_MODE_HOGWILD handles with fp32 rows keep
- * FAT rows (ge_context_layout.row_stride = dim + 4, a row's bias at [dim]): a row table id returns the fat table and
- * *count = rows x row_stride; a bias table id returns the fat table it lives in (FBIAS -> FOCUS, GSQ_CBIAS -> GSQ_CONTEXT ...),
- * the bias of row r being element r * row_stride + dim.  bf16 row tables are refused (ge_glove_context_layout). */
+ * FAT rows (row width dim + 4, a row's bias at [dim]) inside records of ge_context_layout.row_stride floats (row | accumulator
+ * row | ...): a row table id returns the address of ITS row in the first record and *count = the floats from there to the end
+ * of its row in the last record; a bias table id returns the row table it lives in (FBIAS -> FOCUS, GSQ_CBIAS -> GSQ_CONTEXT
+ * ...), the bias of row r being element r * row_stride + dim.  bf16 row tables are refused (ge_glove_context_layout). */
 ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *count);
 
 /* The order in which ONE worker (cfg.workers = 1) walks the nonzeros in epoch `iteration` of a HOGWILD handle:
@@ -323,27 +326,8 @@ ge_status ge_sim_pairs_get(const ge_sim_pairs *r, int64_t *count, const int32_t 
 void ge_sim_pairs_destroy(ge_sim_pairs *r);
 
 /* ------------------------------------------------------------------------------------------ */
-/* Multi-GPU context exchange (no counterpart in the single-JVM reference).  The context side is
- * replicated per GPU; after a local epoch each rank all-reduces the DELTA of its replica (RCCL, by the caller:
- * torch.distributed in geglove/parallel.py).  This entry point is the elementwise half, one pass over device
- * memory on `stream` (asynchronous):
- *   land != 0:  table += wire - own, base += wire - own     `wire` holds the all-reduced sum of every rank's bf16
- *                                        delta, `own` this rank's part of it: the difference is what the others sent;
- *   take != 0:  d = bf16(table - base) (before landing); wire = own = d; base += d.
- * `base` starts as a copy of the table and is then always  consensus + this rank's deltas in flight  (consensus =
- * start + every landed sum, identical on all ranks): what bf16 drops from a delta stays in table - base and leaves with
- * the next one, so replicas differ by what is in flight plus one rounding however long the run.  wire/own are bf16
- * (round to nearest even), 16-byte aligned like table/base; count = elements. */
-ge_status ge_exchange_turn(float *table, float *base, uint16_t *wire, uint16_t *own, int64_t count,
-                           int32_t land, int32_t take, void *stream);
-
-/* ge_exchange_turn over the row part of a table of FAT rows (see ge_context_layout.row_stride): `rows` rows of `row_stride`
- * floats of which the first `cols` take part; the others (the row's bias, which merges by another rule, and the padding) are
- * left untouched and their wire / own slots zeroed on a take.  table, base, wire, own all hold rows x row_stride elements. */
-ge_status ge_exchange_turn_rows(float *table, float *base, uint16_t *wire, uint16_t *own, int64_t rows, int32_t row_stride,
-                                int32_t cols, int32_t land, int32_t take, void *stream);
-
-/* Where the context rows of a handle live on the device (for the exchange above and below).  dtype GE_DTYPE_F32:
+/* ------------------------------------------------------------------------------------------ */
+/* Where the context rows of a handle live on the device (ge_sync works on these; tests and tools wrap them zero-copy).  dtype GE_DTYPE_F32:
  * `table` is float[vocab_size*row_stride] and the hub fields are NULL/0.  GE_DTYPE_BF16: `table` is bf16[vocab_size*dim];
  * a column v with hub_index[v] >= 0 keeps its current value in hub_rows[hub_index[v]*dim ..] (fp32 master row; the
  * bf16 copy of such a row is stale until extraction).  Which columns are hubs is decided per handle from ITS nonzeros. */
@@ -360,12 +344,68 @@ typedef struct {
 } ge_context_layout;
 ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out);
 
-/* ge_exchange_turn for a GE_DTYPE_BF16 context table: same land / take on the row values described by
- * ge_context_layout.  `base` is float[vocab_size*dim] for EVERY row (start: the row values widened), wire / own are
- * bf16[vocab_size*dim].  Landed ordinary rows are re-narrowed with stochastic rounding drawn from `seed` (a new one
- * every turn); that rounding is part of table - base and is fed back with the next delta. */
+/* The elementwise half of one exchange step for a GE_DTYPE_BF16 context table (what ge_sync runs for bf16 rows; exported for
+ * its parity test).  One pass over device memory on `stream`, asynchronous:
+ *   land != 0:  row value += wire - own, base += wire - own   (`wire` = the all-reduced sum of every rank's bf16 delta, `own`
+ *               this rank's part of it: the difference is what the others sent);
+ *   take != 0:  d = bf16(row value - base) (before landing); wire = own = d; base += d.
+ * A row's value lives in hub_rows[hub_index[v]] (fp32 master) when the column is a hub on this rank, else in the bf16 table.
+ * `base` is float[vocab_size*dim] for EVERY row (start: the row values widened), wire / own are bf16[vocab_size*dim].  Landed
+ * ordinary rows are re-narrowed with stochastic rounding drawn from `seed` (a new one every turn); that rounding is part of
+ * value - base and is fed back with the next delta. */
 ge_status ge_exchange_turn_bf16(uint16_t *table, float *hub_rows, const int32_t *hub_index, int32_t vocab_size, int32_t dim,
                                 float *base, uint16_t *wire, uint16_t *own, int32_t land, int32_t take, uint32_t seed, void *stream);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Multi-GPU trainer behind the C ABI (north_star: "rows shard across the 8 GPUs of one node with a periodic
+ * RCCL all-reduce of the context factors").  One ge_glove handle per GPU (cfg.device, cfg.row_begin/row_end = its block of
+ * focus rows, its nonzeros), one ge_sync per handle; the host runs the handles in lockstep -- one process per GPU, or one
+ * thread per GPU inside one process (the JVM) -- and after every ge_glove_epoch calls ge_sync_turn (or ge_sync_sync).
+ * The reference is a single JVM and has no counterpart; the merge rule is product semantics and lives in the library:
+ *   context rows and both AdaGrad accumulators: the ranks' deltas ADD; cBias: the MEAN over the ranks that moved the element
+ *   (the reference updates biases without a learning rate, J/opt/grad/Adagrad.java:88-89); the accumulators are reconciled
+ *   only every accum_every-th exchange.  GE_MODE_HOGWILD + GE_OPT_ADAGRAD handles (fp32 or bf16 rows). */
+typedef struct ge_sync ge_sync;
+
+/* A collective supplied by the host instead of RCCL (tests: torch.distributed / gloo with two ranks on one GPU; the C++ CLI:
+ * N ranks inside one process).  buf is DEVICE memory of `count` elements of GE_DTYPE_F32 or GE_DTYPE_BF16; the library has
+ * drained its stream before it calls.  start: begin summing buf over all ranks in place, *ticket identifies the operation;
+ * wait: return when that sum is in buf; broadcast: every rank's buf becomes rank src's (blocking).  Return GE_OK or GE_ERR_*. */
+typedef struct {
+    void *user;
+    ge_status (*start)(void *user, void *buf, int64_t count, int32_t dtype, void **ticket);
+    ge_status (*wait)(void *user, void *ticket);
+    ge_status (*broadcast)(void *user, void *buf, int64_t count, int32_t dtype, int32_t src);
+} ge_transport;
+
+typedef struct {
+    int32_t world, rank;           /* ranks = GPUs; world == 1: every call is a no-op                                        */
+    int32_t wire;                  /* GE_DTYPE_BF16: the deltas of the row / accumulator tables travel as bf16 (half the bytes
+                                      over xGMI; what the rounding drops is fed back with the next delta); GE_DTYPE_F32        */
+    int32_t accum_every;           /* accumulators every Nth exchange (0 = 4)                                                  */
+    const ge_transport *transport; /* NULL: RCCL (the library opens librccl.so.1 at run time) ...                              */
+    const void *rccl_id;           /* ... with this 128-byte ncclUniqueId: ge_rccl_unique_id on rank 0, handed to every rank   */
+} ge_sync_cfg;
+
+ge_status ge_rccl_unique_id(void *id128);
+int32_t ge_sync_cfg_size(void);
+/* Collective: every rank calls it (RCCL: ncclCommInitRank inside).  The base of every table is its value NOW. */
+ge_status ge_sync_create(ge_glove *h, const ge_sync_cfg *cfg, ge_sync **out);
+/* begin = take: the deltas since the last take go on the wire (everything != 0: accumulators too), asynchronously on RCCL's
+ * own stream.  finish = land: waits for them and adds what the OTHER ranks sent.  turn = finish, then begin: the all-reduce of
+ * step k runs under ge_glove_epoch of step k+1 (launch that epoch with cfg.workers = -256 so RCCL's kernels find room), and a
+ * rank sees the others' moves one step late.  sync = turn, then finish: exact replicas after every step, nothing left in flight.  All enqueue on the
+ * handle's stream and return; none blocks the host with RCCL. */
+ge_status ge_sync_begin(ge_sync *s, int32_t everything);
+ge_status ge_sync_finish(ge_sync *s);
+ge_status ge_sync_turn(ge_sync *s);
+ge_status ge_sync_sync(ge_sync *s);
+/* Ends a run: lands what is in flight, exchanges everything not sent yet, then every rank takes rank src's fp32 tables. */
+ge_status ge_sync_replicate(ge_sync *s, int32_t src);
+/* n host doubles summed (op 0) or maximised (op 1) over the ranks through RCCL: the epoch's cost (Optimizer.java:94-96 needs
+ * the sum over all jobs), BookmarkColoring's max over shards.  Blocking. */
+ge_status ge_sync_allreduce_f64(ge_sync *s, double *values, int32_t n, int32_t op);
+void ge_sync_destroy(ge_sync *s);
 
 /* ------------------------------------------------------------------------------------------ */
 const char *ge_last_error(void);     /* message of the calling thread's last failed call */

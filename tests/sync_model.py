@@ -1,0 +1,73 @@
+"""A model of the multi-GPU context exchange in plain torch ops on HOST tensors (test infrastructure).
+
+The product's exchange lives behind the C ABI (ge_sync_*, graph-embeddings_amd/csrc/sync.hip: device kernels + RCCL).  This
+file restates its merge rule -- deltas of the context rows and the AdaGrad accumulators add, cBias takes the mean over the ranks
+that moved the element, accumulators only every lazy_every-th exchange, take / land with a base that carries what is in flight --
+so that (a) world_size-2 gloo tests can run the N > 1 logic on a machine without a GPU and (b) the GPU tests have something
+independent to hold ge_sync against.  It never runs in the product."""
+import torch
+import torch.distributed as dist
+
+
+class SyncModel:
+    def __init__(self, sums, means, lazy_sums=(), lazy_every=4, wire="bf16", group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.wire = wire
+        self.lazy_every = max(1, int(lazy_every))
+        self.calls = 0
+        self.ent = ([dict(t=t, o=t.clone(), mean=False, lazy=False, work=None) for t in sums] +
+                    [dict(t=t, o=t.clone(), mean=False, lazy=True, work=None) for t in lazy_sums] +
+                    [dict(t=t, o=t.clone(), mean=True, lazy=False, work=None) for t in means])
+        for e in self.ent:
+            narrow = wire == "bf16" and not e["mean"]
+            e["w"] = torch.empty(e["t"].shape, dtype=torch.bfloat16 if narrow else e["t"].dtype)
+            e["own"] = torch.empty_like(e["w"]); e["cnt"] = None
+
+    def _turn(self, land, take, everything=False):
+        """o = the consensus c, own = this rank's delta in flight (csrc/sync.hip, k_sync_turn)."""
+        if self.world == 1:
+            return
+        due = False
+        if take:
+            self.calls += 1
+            due = everything or self.calls % self.lazy_every == 0
+        for e in self.ent:
+            do_land = land and e["work"] is not None
+            do_take = take and (due or not e["lazy"])
+            if not (do_land or do_take):
+                continue
+            t, c, w, own = e["t"], e["o"], e["w"], e["own"]
+            resid = t - c
+            if do_land:
+                for x in e["work"]:
+                    x.wait()
+                e["work"] = None
+                m = w.to(torch.float32)
+                if e["mean"]:
+                    m = m / e["cnt"].clamp(min=1.0)
+                c.add_(m)
+                resid = resid - own.to(torch.float32)
+                t.copy_(c + resid)
+            if do_take:
+                w.copy_(resid); own.copy_(w)
+                work = []
+                if e["mean"]:
+                    e["cnt"] = own.ne(0).to(torch.float32)
+                    work.append(dist.all_reduce(e["cnt"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                work.append(dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                e["work"] = work
+
+    def begin(self, everything=False): self._turn(False, True, everything)
+    def finish(self): self._turn(True, False)
+    def turn(self, everything=False): self._turn(True, True, everything)
+    def sync(self): self.turn(); self.finish()
+
+    def replicate(self, src=0):
+        if self.world == 1:
+            return
+        self.turn(everything=True)
+        self.finish()
+        for e in self.ent:
+            dist.broadcast(e["t"], src=src, group=self.group)
+            e["o"].copy_(e["t"])

@@ -1,9 +1,9 @@
 #!/bin/bash
-# default layout vs round-1 fixed cuts vs interleaved records, alternating fresh processes (compare only in alternation)
+# default layout vs round-1 fixed cuts vs separate_tablesd records, alternating fresh processes (compare only in alternation)
 set -o pipefail
 O=gpurun_out/r02/ab; mkdir -p $O
 for i in 1 2 3; do
-  for L in default fixed_cuts interleave; do
+  for L in default fixed_cuts separate_tables; do
     A=""; [ $L != default ] && A="--layout $L"
     python bench.py --no-cpu-baseline --steps 5 $A > $O/${L}_$i.json 2> $O/${L}_$i.err || { tail -5 $O/${L}_$i.err; exit 1; }
   done

@@ -2,7 +2,7 @@
 set -o pipefail
 O=gpurun_out/r02/ab2; mkdir -p $O
 for i in 1 2 3 4 5 6; do
-  for L in default interleave; do
+  for L in default separate_tables; do
     A=""; [ $L != default ] && A="--layout $L"
     python bench.py --no-cpu-baseline --steps 5 $A > $O/${L}_$i.json 2> $O/${L}_$i.err || { tail -5 $O/${L}_$i.err; exit 1; }
   done
