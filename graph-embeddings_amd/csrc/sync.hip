@@ -24,7 +24,9 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 // glove.hip
@@ -145,8 +147,23 @@ unsigned grid_for(int64_t n, int cus) { return (unsigned)std::max<int64_t>(1, st
 
 }  // namespace
 
+// N ranks inside ONE process (one host thread each), on any number of devices: buffers meet in host memory.  What the C++
+// CLI uses when it has fewer GPUs than ranks, and what lets one GPU rehearse an N-rank run without RCCL.
+struct ge_local_group {
+    int world = 0;
+    std::mutex m; std::condition_variable cv; int arrived = 0; unsigned long generation = 0;
+    std::vector<std::vector<unsigned char>> stage;        // one host buffer per rank
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const unsigned long g = generation;
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != g; });
+    }
+};
+
 struct ge_sync {
     ge_glove *h = nullptr;
+    ge_local_group *loop = nullptr;
     ge_sync_cfg cfg{};
     ge_transport tr{};              // callbacks (copied); tr.start == nullptr: RCCL
     ncclComm_t comm = nullptr;
@@ -167,6 +184,41 @@ struct ge_sync {
 };
 
 namespace {
+
+// sum of every rank's device buffer, in rank order, back into each rank's buffer (blocking; the caller's stream is idle)
+ge_status local_allreduce(ge_local_group *g, int rank, void *buf, int64_t count, int32_t dtype, bool bcast, int src) {
+    const size_t bytes = (size_t)count * (dtype == GE_DTYPE_BF16 ? 2 : dtype == 2 ? 8 : 4);       // dtype 2: host doubles (scalars)
+    std::vector<unsigned char> &mine = g->stage[(size_t)rank];
+    mine.resize(bytes);
+    if (dtype == 2) std::memcpy(mine.data(), buf, bytes);
+    else GE_HIP(hipMemcpy(mine.data(), buf, bytes, hipMemcpyDeviceToHost));
+    g->barrier();
+    std::vector<unsigned char> out(bytes);
+    if (bcast) std::memcpy(out.data(), g->stage[(size_t)src].data(), bytes);
+    else if (dtype == GE_DTYPE_F32) {
+        float *o = (float *)out.data();
+        for (int64_t k = 0; k < count; ++k) { float a = 0.0f; for (int r = 0; r < g->world; ++r) a += ((const float *)g->stage[(size_t)r].data())[k]; o[k] = a; }
+    } else if (dtype == GE_DTYPE_BF16) {
+        uint16_t *o = (uint16_t *)out.data();
+        for (int64_t k = 0; k < count; ++k) {
+            float a = 0.0f;
+            for (int r = 0; r < g->world; ++r) { const uint32_t hbits = ((const uint16_t *)g->stage[(size_t)r].data())[k]; float f; const uint32_t u = hbits << 16; std::memcpy(&f, &u, 4); a += f; }
+            uint32_t u; std::memcpy(&u, &a, 4);
+            o[k] = (uint16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? ((u >> 16) | 0x40u) : ((u + 0x7fffu + ((u >> 16) & 1u)) >> 16));
+        }
+    } else {
+        double *o = (double *)out.data();
+        for (int64_t k = 0; k < count; ++k) {
+            double a = ((const double *)g->stage[0].data())[k];
+            for (int r = 1; r < g->world; ++r) { const double v = ((const double *)g->stage[(size_t)r].data())[k]; a = src == 1 ? std::max(a, v) : a + v; }   // src doubles as the op for scalars
+            o[k] = a;
+        }
+    }
+    g->barrier();                                                        // every rank has read the stage
+    if (dtype == 2) std::memcpy(buf, out.data(), bytes);
+    else GE_HIP(hipMemcpy(buf, out.data(), bytes, hipMemcpyHostToDevice));
+    return GE_OK;
+}
 
 ge_status launch_turn(ge_sync *s, Entry &e, bool land, bool take) {
     if (!land && !take) return GE_OK;
@@ -191,7 +243,14 @@ ge_status launch_turn(ge_sync *s, Entry &e, bool land, bool take) {
 // starts the all-reduce of every entry taken in this call
 ge_status start_reduce(ge_sync *s, const std::vector<Entry *> &taken) {
     if (taken.empty()) return GE_OK;
-    if (!s->tr.start) {
+    if (s->loop) {
+        GE_HIP(hipStreamSynchronize(s->main));
+        for (Entry *e : taken) {
+            ge_status st = local_allreduce(s->loop, s->cfg.rank, e->wire, e->n, e->w16 ? GE_DTYPE_BF16 : GE_DTYPE_F32, false, 0);
+            if (st == GE_OK && e->mean) st = local_allreduce(s->loop, s->cfg.rank, e->cnt, e->n, GE_DTYPE_F32, false, 0);
+            if (st != GE_OK) return st;
+        }
+    } else if (!s->tr.start) {
         GE_HIP(hipEventRecord(s->ev_taken, s->main));
         GE_HIP(hipStreamWaitEvent(s->side, s->ev_taken, 0));
         for (Entry *e : taken) {
@@ -214,7 +273,7 @@ ge_status start_reduce(ge_sync *s, const std::vector<Entry *> &taken) {
 ge_status wait_reduce(ge_sync *s) {
     bool any = false;
     for (Entry &e : s->ent) any = any || e.in_flight;
-    if (!any) return GE_OK;
+    if (!any || s->loop) return GE_OK;
     if (!s->tr.start) { GE_HIP(hipStreamWaitEvent(s->main, s->ev_reduced, 0)); return GE_OK; }
     for (Entry &e : s->ent) {
         if (!e.in_flight) continue;
@@ -250,6 +309,16 @@ extern "C" {
 
 int32_t ge_sync_cfg_size(void) { return (int32_t)sizeof(ge_sync_cfg); }
 
+ge_status ge_local_group_create(int32_t world, ge_local_group **out) {
+    if (!out || world < 1) return ge::fail(GE_ERR_ARG, "ge_local_group_create: world must be >= 1");
+    ge_local_group *g = new (std::nothrow) ge_local_group();
+    if (!g) return ge::fail(GE_ERR_OOM, "host allocation failed");
+    g->world = world; g->stage.resize((size_t)world);
+    *out = g;
+    return GE_OK;
+}
+void ge_local_group_destroy(ge_local_group *g) { delete g; }
+
 ge_status ge_rccl_unique_id(void *id128) {
     if (!id128) return ge::fail(GE_ERR_ARG, "null id buffer");
     if (!rccl().ok) return ge::fail(GE_ERR_HIP, "RCCL is not available (librccl.so.1 could not be loaded)");
@@ -257,6 +326,37 @@ ge_status ge_rccl_unique_id(void *id128) {
     GE_NCCL(rccl().GetUniqueId(&id));
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
     std::memcpy(id128, &id, sizeof(id));
+    return GE_OK;
+}
+
+// One rank, one GPU: RCCL is opened, a communicator of size 1 made, a sum and a broadcast run through it and compared
+// with what went in.  What a single-GPU box can check of the RCCL path (symbols, calling convention, stream order).
+ge_status ge_rccl_selftest(int32_t device) {
+    ge_status st = ge::select_device(device);
+    if (st != GE_OK) return st;
+    if (!rccl().ok) return ge::fail(GE_ERR_HIP, "RCCL is not available (librccl.so.1 could not be loaded)");
+    ncclUniqueId id;
+    GE_NCCL(rccl().GetUniqueId(&id));
+    ncclComm_t comm = nullptr;
+    GE_NCCL(rccl().CommInitRank(&comm, 1, id, 0));
+    const int n = 4096;
+    float *d = nullptr; hipStream_t side = nullptr;
+    std::vector<float> h((size_t)n), back((size_t)n);
+    for (int k = 0; k < n; ++k) h[(size_t)k] = 0.25f * (float)k - 7.0f;
+    hipError_t he = hipMalloc((void **)&d, sizeof(float) * n);
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipMemcpyAsync(d, h.data(), sizeof(float) * n, hipMemcpyHostToDevice, side);
+    ncclResult_t nr = ncclSuccess;
+    if (he == hipSuccess) nr = rccl().AllReduce(d, d, (size_t)n, ncclFloat32, ncclSum, comm, side);
+    if (he == hipSuccess && nr == ncclSuccess) nr = rccl().Broadcast(d, d, (size_t)n, ncclFloat32, 0, comm, side);
+    if (he == hipSuccess && nr == ncclSuccess) he = hipMemcpyAsync(back.data(), d, sizeof(float) * n, hipMemcpyDeviceToHost, side);
+    if (he == hipSuccess && nr == ncclSuccess) he = hipStreamSynchronize(side);
+    if (d) (void)hipFree(d);
+    if (side) (void)hipStreamDestroy(side);
+    (void)rccl().CommDestroy(comm);
+    if (nr != ncclSuccess) return ge::fail(GE_ERR_HIP, "RCCL self-test: %s", rccl().GetErrorString(nr));
+    if (he != hipSuccess) return ge::fail(GE_ERR_HIP, "RCCL self-test: %s", hipGetErrorString(he));
+    if (std::memcmp(h.data(), back.data(), sizeof(float) * n) != 0) return ge::fail(GE_ERR_STATE, "RCCL self-test: a one-rank sum changed the data");
     return GE_OK;
 }
 
@@ -288,7 +388,9 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
     if (opt != GE_OPT_ADAGRAD) return ge::fail(GE_ERR_STATE, "the context exchange (which deltas add, which average) is defined for adagrad only");
     ge_sync *s = new (std::nothrow) ge_sync();
     if (!s) return ge::fail(GE_ERR_OOM, "host allocation failed");
-    s->h = h; s->cfg = *cfg; s->cfg.transport = nullptr; s->cfg.rccl_id = nullptr;
+    s->h = h; s->cfg = *cfg; s->cfg.transport = nullptr; s->cfg.rccl_id = nullptr; s->cfg.local_group = nullptr;
+    s->loop = cfg->local_group;
+    if (s->loop && s->loop->world != cfg->world) { delete s; return ge::fail(GE_ERR_ARG, "local group has %d ranks, cfg.world is %d", s->loop->world, cfg->world); }
     if (s->cfg.accum_every == 0) s->cfg.accum_every = 4;
     if (cfg->transport) s->tr = *cfg->transport;
     s->main = (hipStream_t)stream; s->device = device;
@@ -327,8 +429,8 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
         }
         GE_TRYS(hipGetLastError());
         GE_TRYS(hipStreamSynchronize(s->main));
-        if (!s->tr.start) {
-            if (!cfg->rccl_id) { ge_sync_destroy(s); return ge::fail(GE_ERR_ARG, "world > 1 needs a transport or an RCCL unique id (ge_rccl_unique_id on rank 0, handed to every rank)"); }
+        if (!s->tr.start && !s->loop) {
+            if (!cfg->rccl_id) { ge_sync_destroy(s); return ge::fail(GE_ERR_ARG, "world > 1 needs a transport, a local group or an RCCL unique id (ge_rccl_unique_id on rank 0, handed to every rank)"); }
             if (!rccl().ok) { ge_sync_destroy(s); return ge::fail(GE_ERR_HIP, "RCCL is not available (librccl.so.1 could not be loaded)"); }
             GE_TRYS(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
             GE_TRYS(hipEventCreateWithFlags(&s->ev_taken, hipEventDisableTiming));
@@ -368,7 +470,10 @@ static ge_status ge_sync_replicate_impl(ge_sync *s, int32_t src) {
         if (e.w16) { GE_HIP(hipMalloc((void **)&tmp, sizeof(float) * (size_t)e.n)); stage = tmp; }
         hipLaunchKernelGGL(k_gather, dim3(grid_for(e.n, s->cus)), dim3(256), 0, s->main, e.table, e.t_stride, e.cols, e.n, stage);
         ge_status r = GE_OK;
-        if (!s->tr.start) {
+        if (s->loop) {
+            if (hipStreamSynchronize(s->main) != hipSuccess) r = ge::fail(GE_ERR_HIP, "replicate: stream synchronize failed");
+            else r = local_allreduce(s->loop, s->cfg.rank, stage, e.n, GE_DTYPE_F32, true, src);
+        } else if (!s->tr.start) {
             hipError_t he = hipEventRecord(s->ev_taken, s->main);
             if (he == hipSuccess) he = hipStreamWaitEvent(s->side, s->ev_taken, 0);
             ncclResult_t nr = he == hipSuccess ? rccl().Broadcast(stage, stage, (size_t)e.n, ncclFloat32, src, s->comm, s->side) : ncclSuccess;
@@ -393,6 +498,8 @@ ge_status ge_sync_replicate(ge_sync *s, int32_t src) { GE_GUARD(ge_sync_replicat
 static ge_status ge_sync_allreduce_f64_impl(ge_sync *s, double *values, int32_t n, int32_t op) {
     if (!s || !values || n < 0) return ge::fail(GE_ERR_ARG, "invalid argument");
     if (s->cfg.world == 1 || n == 0) return GE_OK;
+    if (op != 0 && op != 1) return ge::fail(GE_ERR_ARG, "op must be 0 (sum) or 1 (max)");
+    if (s->loop) return local_allreduce(s->loop, s->cfg.rank, values, n, 2, false, op);
     if (s->tr.start) return ge::fail(GE_ERR_STATE, "ge_sync_allreduce_f64 runs over RCCL; a host that brought its own transport reduces its scalars there");
     if (op != 0 && op != 1) return ge::fail(GE_ERR_ARG, "op must be 0 (sum) or 1 (max)");
     GE_HIP(hipSetDevice(s->device));

@@ -23,7 +23,9 @@
 #include <map>
 #include <set>
 #include <iterator>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -235,7 +237,9 @@ struct Configuration {
              long long seed = 0; bool has_seed = false; int id = 0; int workers = 0;
              // Hogwild tuning (ge_glove_cfg: 0 = library default), layout: list of fixed_cuts | plain_long_rows | separate_tables
              double hot_theta = 0, stale_budget = 0; int flush_every = 0, blocks_per_cu = 0, layout_flags = 0;
-             long long bca_table_slots = 0, bca_pool_entries = 0; } device;
+             long long bca_table_slots = 0, bca_pool_entries = 0;
+             // multi-GPU: gpus ranks, one thread each, rows sharded, context exchanged through ge_sync
+             int gpus = 1, accum_every = 0; std::string exchange = "overlap", transport = "auto", wire = "bf16"; } device;
     std::vector<std::string> ignored_keys;     // legacy keys of the shipped YAMLs that the bean does not know
 
     int getThreads() const {       // Configuration.java:71-73
@@ -322,6 +326,11 @@ struct Configuration {
                     else if (q.first == "dtype") c.device.dtype = q.second.scalar;
                     else if (q.first == "save_coo") c.device.save_coo = q.second.scalar;      // COO checkpoint
                     else if (q.first == "load_coo") c.device.load_coo = q.second.scalar;
+                    else if (q.first == "gpus") c.device.gpus = std::max(1, (int)num(&q.second));
+                    else if (q.first == "exchange") c.device.exchange = q.second.scalar;        // overlap | sync
+                    else if (q.first == "transport") c.device.transport = q.second.scalar;      // auto | rccl | host
+                    else if (q.first == "wire") c.device.wire = q.second.scalar;                // bf16 | f32
+                    else if (q.first == "accum_every") c.device.accum_every = (int)num(&q.second);
                     else if (q.first == "hot_theta") c.device.hot_theta = num(&q.second);
                     else if (q.first == "stale_budget") c.device.stale_budget = num(&q.second);
                     else if (q.first == "flush_every") c.device.flush_every = (int)num(&q.second);
@@ -698,7 +707,7 @@ struct CoOccurrenceMatrix {                     // J/util/CoOccurrenceMatrix.jav
 
 class BookmarkColoring : public CoOccurrenceMatrix {        // J/bca/BookmarkColoring.java
 public:
-    BookmarkColoring(const InMemoryGraph &graph, const Configuration &config) : graph_(graph) {
+    BookmarkColoring(const InMemoryGraph &graph, const Configuration &config, int32_t row_begin = 0, int32_t row_end = 0, int device = -1) : graph_(graph) {
         ge_csr out{graph.V, graph.out_ptr.data(), graph.out_idx.data(), graph.out_w.data()};
         ge_csr in{graph.V, graph.in_ptr.data(), graph.in_idx.data(), graph.in_w.data()};
         ge_bca_cfg cfg{};
@@ -706,7 +715,8 @@ public:
         std::string n = config.getNormalize(); for (auto &ch : n) ch = (char)std::tolower((unsigned char)ch);
         if (n == "none") cfg.normalize = GE_NORM_NONE; else if (n == "unity") cfg.normalize = GE_NORM_UNITY;
         else if (n == "counts") cfg.normalize = GE_NORM_COUNTS; else throw std::invalid_argument("No enum constant BCANormalization." + n);
-        cfg.device = config.device.id;
+        cfg.device = device >= 0 ? device : config.device.id;
+        cfg.row_begin = row_begin; cfg.row_end = row_end;          // a shard of the bookmarks (multi-GPU); 0,0 = all
         cfg.table_slots = config.device.bca_table_slots; cfg.pool_entries = config.device.bca_pool_entries;
         ge_coo *h = nullptr;
         check(ge_bca_build(&out, &in, &cfg, &h));
@@ -785,6 +795,63 @@ private:
     int32_t V_ = 0; double max_ = 0;
     std::vector<int32_t> I_, J_; std::vector<float> X_;
     std::vector<std::string> keys_; std::vector<int8_t> types_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU: `device: {gpus: N}`.  One host thread per rank; rank g uses HIP device (id + g) mod #devices,
+// owns a contiguous block of bookmarks / focus rows, and the ranks' context sides are reconciled through ge_sync.
+// With one device per rank the exchange runs over RCCL; with fewer devices (a rehearsal) the ranks meet in host memory
+// (ge_local_group).  `device.transport: rccl | host` forces either.
+// ------------------------------------------------------------------------------------------------
+inline void shard_rows(int32_t V, int world, int rank, int32_t &begin, int32_t &end) {
+    const int32_t base = V / world, rem = V % world;
+    begin = rank * base + std::min(rank, (int)rem);
+    end = begin + base + (rank < rem ? 1 : 0);
+}
+inline int rank_device(const Configuration &config, int rank) {
+    const int n = std::max(1, (int)ge_device_count());
+    return (config.device.id + rank) % n;
+}
+template <typename F> void run_ranks(int world, F body) {               // body(rank); the first exception is rethrown
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err((size_t)world);
+    for (int r = 0; r < world; ++r) th.emplace_back([&, r] { try { body(r); } catch (...) { err[(size_t)r] = std::current_exception(); } });
+    for (auto &t : th) t.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
+// BookmarkColoring built in `gpus` shards of bookmarks, one per rank (no collective: the rows are independent jobs,
+// J/bca/BookmarkColoring.java:58-71; max = the max over the shards, :97), concatenated in rank order = bookmark order.
+class ShardedBookmarkColoring : public CoOccurrenceMatrix {
+public:
+    ShardedBookmarkColoring(const InMemoryGraph &graph, const Configuration &config) : graph_(graph) {
+        const int world = config.device.gpus;
+        std::vector<std::unique_ptr<BookmarkColoring>> part((size_t)world);
+        run_ranks(world, [&](int r) {
+            int32_t b, e; shard_rows(graph.V, world, r, b, e);
+            if (b < e) part[(size_t)r].reset(new BookmarkColoring(graph, config, b, e, rank_device(config, r)));
+        });
+        for (auto &p : part) if (p) {
+            const size_t n = (size_t)p->coOccurrenceCount();
+            I_.insert(I_.end(), p->dataI(), p->dataI() + n); J_.insert(J_.end(), p->dataJ(), p->dataJ() + n); X_.insert(X_.end(), p->dataX(), p->dataX() + n);
+            max_ = std::max(max_, p->max());
+        }
+    }
+    int vocabSize() const override { return graph_.V; }
+    double max() const override { return max_; }
+    std::string getKey(int index) const override { return graph_.keys[(size_t)index]; }
+    int8_t getType(int index) const override { return graph_.types[(size_t)index]; }
+    int cIdx_I(int i) const override { return I_[(size_t)i]; }
+    int cIdx_J(int j) const override { return J_[(size_t)j]; }
+    float cIdx_C(int i) const override { return X_[(size_t)i]; }
+    int coOccurrenceCount() const override { return (int)I_.size(); }
+    void shuffle() override {}
+    const int32_t *dataI() const override { return I_.data(); }
+    const int32_t *dataJ() const override { return J_.data(); }
+    const float *dataX() const override { return X_.data(); }
+private:
+    const InMemoryGraph &graph_;
+    std::vector<int32_t> I_, J_; std::vector<float> X_; double max_ = 0;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -872,6 +939,119 @@ struct AMSGrad : Adagrad {
     AMSGrad(const CoOccurrenceMatrix &m, const Configuration &c, CostFunction cf, void (*pr)(int, double, double) = nullptr) : Adagrad(m, c, cf, pr, GE_OPT_AMSGRAD, "AMSGrad") {}
 };
 
+// The trainer over `gpus` ranks (AdaGrad; the exchange's merge rule is defined for it): every rank thread owns a ge_glove
+// handle for its block of focus rows and its nonzeros plus a ge_sync; the epoch loop of Optimizer.optimize runs in lockstep,
+// the cost of an epoch is the sum over the ranks (Optimizer.java:89-96), and the result is assembled from every rank's focus
+// rows and rank 0's context rows after ge_sync_replicate.
+class ShardedAdagrad : public IOptimizer {
+public:
+    ShardedAdagrad(const CoOccurrenceMatrix &m, const Configuration &config, CostFunction cf, void (*progress)(int, double, double) = nullptr)
+        : m_(m), config_(config), cf_(cf), progress_(progress) {
+        std::string om = config.opt.method; for (auto &ch : om) ch = (char)std::toupper((unsigned char)ch);
+        if (om != "ADAGRAD") throw std::invalid_argument("device.gpus > 1 runs opt.method adagrad only (the exchange's merge rule is defined for it)");
+        if (config.device.mode == "deterministic") throw std::invalid_argument("device.gpus > 1 needs device.mode hogwild");
+    }
+    std::string getName() const override { return "Adagrad"; }
+    std::vector<double> extractResult() override { return result_; }
+    Optimum optimize() override {
+        const int world = config_.device.gpus, V = m_.vocabSize(), D = config_.dim;
+        const int64_t N = m_.coOccurrenceCount();
+        const bool overlap = config_.device.exchange != "sync";
+        const bool use_rccl = config_.device.transport == "rccl" || (config_.device.transport == "auto" && ge_device_count() >= world);
+        ge_local_group *grp = nullptr;
+        unsigned char id[128] = {0};
+        if (use_rccl) check(ge_rccl_unique_id(id)); else check(ge_local_group_create(world, &grp));
+        struct GroupDel { ge_local_group *g; ~GroupDel() { if (g) ge_local_group_destroy(g); } } group_guard{grp};
+        const long long seed = config_.device.has_seed ? config_.device.seed : (long long)(std::time(nullptr)) * 1000LL;
+        Optimum opt;
+        result_.assign((size_t)V * (size_t)D, 0.0);
+        std::vector<double> cost((size_t)world, 0.0);
+        std::vector<float> context0;
+        Barrier bar(world);
+        bool stop = false; double finalCost = 0, prevCost = 0;
+        run_ranks(world, [&](int r) {
+            try {
+            int32_t rb, re; shard_rows(V, world, r, rb, re);
+            // the matrix is grouped by row (BookmarkColoring emits bookmark after bookmark): a rank's nonzeros are one range
+            const int32_t *I = m_.dataI();
+            const int64_t lo = std::lower_bound(I, I + N, rb) - I, hi = std::lower_bound(I, I + N, re) - I;
+            if (!std::is_sorted(I, I + N)) throw std::invalid_argument("device.gpus > 1 needs the co-occurrence matrix grouped by row");
+            ge_glove_cfg cfg;
+            ge_glove_cfg_default(&cfg);
+            cfg.vocab_size = V; cfg.dim = D; cfg.nnz = hi - lo;
+            cfg.cost = cf_ == CostFunction::GLOVE ? GE_COST_GLOVE : GE_COST_PGLOVE;
+            cfg.xmax = m_.max(); cfg.seed = seed; cfg.threads = 1;
+            cfg.mode = GE_MODE_HOGWILD; cfg.shuffle = GE_SHUFFLE_DEVICE;
+            cfg.hot_columns = config_.device.hot == "none" ? GE_HOT_NONE : config_.device.hot == "all" ? GE_HOT_ALL : GE_HOT_AUTO;
+            cfg.workers = config_.device.workers ? config_.device.workers : (overlap && use_rccl ? -256 : 0);   // room for RCCL's kernels beside the epoch
+            cfg.emb_dtype = config_.device.dtype == "bf16" ? GE_DTYPE_BF16 : GE_DTYPE_F32;
+            cfg.device = rank_device(config_, r);
+            cfg.row_begin = rb; cfg.row_end = re;
+            cfg.hot_theta = (float)config_.device.hot_theta; cfg.stale_budget = (float)config_.device.stale_budget;
+            cfg.flush_every = config_.device.flush_every; cfg.blocks_per_cu = config_.device.blocks_per_cu; cfg.layout_flags = config_.device.layout_flags;
+            ge_glove *h = nullptr;
+            check(ge_glove_create(&cfg, m_.dataI() + lo, m_.dataJ() + lo, m_.dataX() + lo, &h));
+            std::unique_ptr<ge_glove, void (*)(ge_glove *)> hg(h, ge_glove_destroy);
+            ge_sync_cfg sc{};
+            sc.world = world; sc.rank = r; sc.wire = config_.device.wire == "f32" ? GE_DTYPE_F32 : GE_DTYPE_BF16;
+            sc.accum_every = config_.device.accum_every; sc.rccl_id = use_rccl ? id : nullptr; sc.local_group = grp;
+            ge_sync *sy = nullptr;
+            check(ge_sync_create(h, &sc, &sy));
+            std::unique_ptr<ge_sync, void (*)(ge_sync *)> sg(sy, ge_sync_destroy);
+            for (int iteration = 0; iteration < config_.opt.maxiter; ++iteration) {
+                double c = 0;
+                check(ge_glove_epoch(h, iteration, &c));
+                check(overlap ? ge_sync_turn(sy) : ge_sync_sync(sy));
+                cost[(size_t)r] = c;
+                bar.wait();
+                if (r == 0) {                                   // Optimizer.optimize's tolerance logic, once for all ranks
+                    double localCost = 0; for (double x : cost) localCost += x;
+                    localCost /= (double)N;
+                    opt.costHistory.push_back(localCost);
+                    const double iterDiff = std::fabs(prevCost - localCost);
+                    if (progress_) progress_(iteration, localCost, iterDiff);
+                    prevCost = localCost;
+                    if (iterDiff <= config_.opt.tolerance) { finalCost = localCost; stop = true; }
+                }
+                bar.wait();
+                if (stop) break;
+            }
+            check(ge_sync_replicate(sy, 0));
+            std::vector<float> focus((size_t)(re - rb) * (size_t)D);
+            if (re > rb) check(ge_glove_get_state(h, GE_STATE_FOCUS, focus.data(), (int64_t)focus.size()));
+            if (r == 0) { context0.resize((size_t)V * (size_t)D); check(ge_glove_get_state(h, GE_STATE_CONTEXT, context0.data(), (int64_t)context0.size())); }
+            bar.wait();
+            for (size_t k = 0; k < focus.size(); ++k) {         // Optimizer.extractResult: (focus + context) / 2 in fp32, widened
+                const size_t g = (size_t)rb * (size_t)D + k;
+                result_[g] = (double)((focus[k] + context0[g]) / 2.0f);
+            }
+            } catch (...) { bar.abandon(); throw; }
+        });
+        opt.result = result_;
+        opt.finalCost = finalCost;
+        return opt;
+    }
+private:
+    struct Barrier {                                            // reusable; abandon() releases everybody when a rank fails
+        explicit Barrier(int n) : n_(n) {}
+        void wait() {
+            std::unique_lock<std::mutex> lk(m_);
+            if (dead_) throw std::runtime_error("another rank failed");
+            const unsigned long g = gen_;
+            if (++count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
+            else cv_.wait(lk, [&] { return gen_ != g || dead_; });
+            if (dead_) throw std::runtime_error("another rank failed");
+        }
+        void abandon() { std::lock_guard<std::mutex> lk(m_); dead_ = true; cv_.notify_all(); }
+        std::mutex m_; std::condition_variable cv_; int n_, count_ = 0; unsigned long gen_ = 0; bool dead_ = false;
+    };
+    const CoOccurrenceMatrix &m_;
+    const Configuration &config_;
+    CostFunction cf_;
+    void (*progress_)(int, double, double);
+    std::vector<double> result_;
+};
+
 // Main.createOptimizer (J/Main.java:107-131)
 inline std::unique_ptr<IOptimizer> createOptimizer(const Configuration &config, const CoOccurrenceMatrix &m,
                                                    void (*progress)(int, double, double) = nullptr) {
@@ -880,6 +1060,7 @@ inline std::unique_ptr<IOptimizer> createOptimizer(const Configuration &config, 
     if (method == "GLOVE") cf = CostFunction::GLOVE; else if (method == "PGLOVE") cf = CostFunction::PGLOVE;
     else throw std::invalid_argument("Invalid cost function");
     std::string om = config.opt.method; for (auto &ch : om) ch = (char)std::toupper((unsigned char)ch);
+    if (config.device.gpus > 1) return std::unique_ptr<IOptimizer>(new ShardedAdagrad(m, config, cf, progress));
     if (om == "ADAGRAD") return std::unique_ptr<IOptimizer>(new Adagrad(m, config, cf, progress));
     if (om == "ADAM") return std::unique_ptr<IOptimizer>(new Adam(m, config, cf, progress));
     if (om == "AMSGRAD") return std::unique_ptr<IOptimizer>(new AMSGrad(m, config, cf, progress));

@@ -47,7 +47,8 @@ static void runProgram(const Configuration &config) {                       // J
         log_info("Rdf2GrphConverter", b);
         std::snprintf(b, sizeof b, "graph: %d vertices, %zu out-neighbour pairs", graph->V, graph->out_idx.size());
         log_info("Rdf2GrphConverter", b);
-        matrix.reset(new BookmarkColoring(*graph, config));
+        if (config.device.gpus > 1) matrix.reset(new ShardedBookmarkColoring(*graph, config));
+        else matrix.reset(new BookmarkColoring(*graph, config));
         if (!config.device.save_coo.empty()) {
             StoredCooMatrix::save(config.device.save_coo, *matrix);
             log_info("BookmarkColoring", "wrote COO checkpoint " + config.device.save_coo);

@@ -366,6 +366,7 @@ ge_status ge_exchange_turn_bf16(uint16_t *table, float *hub_rows, const int32_t 
  *   (the reference updates biases without a learning rate, J/opt/grad/Adagrad.java:88-89); the accumulators are reconciled
  *   only every accum_every-th exchange.  GE_MODE_HOGWILD + GE_OPT_ADAGRAD handles (fp32 or bf16 rows). */
 typedef struct ge_sync ge_sync;
+typedef struct ge_local_group ge_local_group;
 
 /* A collective supplied by the host instead of RCCL (tests: torch.distributed / gloo with two ranks on one GPU; the C++ CLI:
  * N ranks inside one process).  buf is DEVICE memory of `count` elements of GE_DTYPE_F32 or GE_DTYPE_BF16; the library has
@@ -385,9 +386,19 @@ typedef struct {
     int32_t accum_every;           /* accumulators every Nth exchange (0 = 4)                                                  */
     const ge_transport *transport; /* NULL: RCCL (the library opens librccl.so.1 at run time) ...                              */
     const void *rccl_id;           /* ... with this 128-byte ncclUniqueId: ge_rccl_unique_id on rank 0, handed to every rank   */
+    ge_local_group *local_group;   /* or: the ranks are threads of THIS process and meet in host memory (any number of devices;
+                                      a rehearsal of an N-rank run on fewer GPUs, blocking, no overlap)                        */
 } ge_sync_cfg;
 
+/* The ranks of one process (one host thread per rank): created once, handed to every rank's ge_sync_cfg, destroyed after the
+ * last ge_sync_destroy. */
+ge_status ge_local_group_create(int32_t world, ge_local_group **out);
+void ge_local_group_destroy(ge_local_group *g);
+
 ge_status ge_rccl_unique_id(void *id128);
+/* Opens RCCL, makes a one-rank communicator on `device`, runs a sum and a broadcast through it and checks the data: what a
+ * single-GPU machine can verify of the RCCL path. */
+ge_status ge_rccl_selftest(int32_t device);
 int32_t ge_sync_cfg_size(void);
 /* Collective: every rank calls it (RCCL: ncclCommInitRank inside).  The base of every table is its value NOW. */
 ge_status ge_sync_create(ge_glove *h, const ge_sync_cfg *cfg, ge_sync **out);

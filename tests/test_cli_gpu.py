@@ -203,3 +203,67 @@ def test_cli_end_to_end_with_similarity_edges(gpu, tmp_path):
     g0, _, _ = _graph_from_host("similar.config.yml", "similar.nt", similarity=False)
     coo0 = O.bca_build(g0["V"], g0["out"], g0["inn"], 0.1, 1e-3, True, O.NORM_NONE)
     assert len(coo0["I"]) < len(coo["I"])
+
+
+def _write_synthetic_nt(path, n_authors=300, n_papers=450, n_venues=8):
+    """The DBLP-like generator as N-Triples with one weighted predicate (vertex ids by first appearance, like the converter)."""
+    g = synth.dblp_like_graph(n_authors, n_papers, n_venues)
+    ptr, idx, _ = g["out"]
+    with open(path, "w") as f:
+        for v in range(g["V"]):
+            for k in range(ptr[v], ptr[v + 1]):
+                f.write("<http://ex.org/n/%d> <http://ex.org/p> <http://ex.org/n/%d> .\n" % (v, idx[k]))
+
+
+_MULTI_YML = """graph: g.nt
+method: pglove
+dim: 24
+threads: 1
+weights:
+  http://ex.org/p: 1
+bca:
+  alpha: 1e-1
+  epsilon: 1e-3
+  directed: true
+opt:
+  method: adagrad
+  tolerance: 0
+  maxiter: 6
+output:
+  uri: [ http://ex.org/n/ ]
+device:
+  mode: hogwild
+  shuffle: device
+  seed: 42
+  save_coo: %s
+%s"""
+
+
+def test_cli_two_ranks_in_one_process(gpu, tmp_path):
+    """`device: {gpus: 2}`: the C++ host runs two ranks (threads) through ge_sync -- on this one-GPU box both ranks use device
+    0 and meet in host memory (ge_local_group); with one device per rank the same code runs over RCCL.  The sharded builder
+    gives the same COO byte for byte; the sharded trainer follows the one-GPU run (cost per epoch, vectors)."""
+    _write_synthetic_nt(tmp_path / "g.nt")
+    runs = {}
+    for name, extra in (("one", ""), ("sync", "  gpus: 2\n  exchange: sync\n  wire: f32\n"), ("overlap", "  gpus: 2\n  exchange: overlap\n")):
+        (tmp_path / (name + ".yml")).write_text(_MULTI_YML % (name + ".gecoo", extra))
+        r = subprocess.run([EXE, "-c", name + ".yml"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        costs = [float(m.group(1)) for m in re.finditer(r"epoch \d+  cost ([0-9.eE+-]+)", r.stdout)]
+        vec = [l for l in (tmp_path / "out" / "g_pglove_exact_directed_0.1_0.001_adagrad_24.vectors.tsv").read_text().splitlines() if not l.startswith("#")]
+        runs[name] = (costs, np.array([[float(x) for x in l.split("\t")] for l in vec]))
+    assert (tmp_path / "one.gecoo").read_bytes() == (tmp_path / "sync.gecoo").read_bytes()          # the builder's shards concatenate to the same matrix
+    one, E1 = runs["one"]
+    assert len(one) == 6
+    for name, tol in (("sync", 0.20), ("overlap", 0.30)):             # a small matrix: the first epochs react most to who sees what when
+        costs, E = runs[name]
+        print("cli gpus 2 %s: cost / one GPU %s" % (name, np.round(np.array(costs) / np.array(one), 3).tolist()))
+        assert len(costs) == 6 and costs[-1] < costs[0]
+        np.testing.assert_allclose(costs[:2], one[:2], rtol=tol)
+        np.testing.assert_allclose(costs[2:], one[2:], rtol=0.06 if name == "sync" else 0.12)    # plumbing test on 750 vertices; the
+        assert E.shape == E1.shape and np.all(np.isfinite(E))                                     # statistics are test_parallel_gpu.py's
+        n1 = E1 / np.linalg.norm(E1, axis=1, keepdims=True); n2 = E / np.linalg.norm(E, axis=1, keepdims=True)
+        iu = np.triu_indices(len(E), 1)
+        rho = np.corrcoef((n1 @ n1.T)[iu], (n2 @ n2.T)[iu])[0, 1]
+        print("cli gpus 2 %s: cost / one GPU %s, pairwise-cosine correlation %.4f" % (name, np.round(np.array(costs) / np.array(one), 3).tolist(), rho))
+        assert rho > 0.9

@@ -50,7 +50,7 @@ def test_c3_standin_trained_vectors_at_dim_200(gpu):
     (invariant to what SGD leaves undetermined): correlation with the sequential Java-order oracle >= 0.995, final
     cost within 3 %."""
     g = synth.dblp_like_graph(10000, 15000, 40)
-    V, D, EP = g["V"], 200, 6
+    V, D, EP = g["V"], 200, 4
     assert V >= 50_000
     cfgb = make_config(D, "pglove")
     bca = geglove.BookmarkColoring(g, cfgb)

@@ -189,7 +189,15 @@ def test_ge_sync_argument_errors(gpu):
     adam = geglove.createOptimizer(make_config(8, "glove", opt="adam", mode="hogwild"), geglove.CooMatrix(50, I, J, X, xmax))
     assert L.ge_sync_create(adam._h, C.byref(cfg), C.byref(h)) == capi.GE_ERR_STATE
     buf = (C.c_char * 128)()
-    assert L.ge_rccl_unique_id(buf) == capi.GE_OK and any(buf.raw)                        # RCCL loads and hands out an id (no communicator is made)
+    assert L.ge_rccl_unique_id(buf) == capi.GE_OK and any(buf.raw)                        # RCCL loads and hands out an id
+
+
+def test_rccl_path_runs_on_one_gpu(gpu):
+    """RCCL refuses two ranks on one device, so a 1-GPU box cannot run the two-rank exchange over it; what it can run is the
+    library's RCCL binding itself: open librccl, ncclCommInitRank (one rank), ncclAllReduce + ncclBroadcast on a side stream,
+    data intact.  The N > 1 data path over RCCL is the driver's 8-GPU bench (bench.py --gpus N)."""
+    from geglove import capi
+    capi.check(capi.lib().ge_rccl_selftest(0))
 
 
 def _np_bf16_rne(x):
