@@ -32,14 +32,30 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     """ctypes mirrors must have the C sizes (the library is the authority: compile a probe)."""
-    src = '#include <stdio.h>\n#include "geglove.h"\nint main(){printf("%zu %zu %zu %zu", sizeof(ge_glove_cfg), sizeof(ge_glove_info), sizeof(ge_csr), sizeof(ge_bca_cfg));return 0;}'
+    src = '#include <stdio.h>\n#include "geglove.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu", sizeof(ge_glove_cfg), sizeof(ge_glove_info), sizeof(ge_csr), sizeof(ge_bca_cfg), sizeof(ge_sync_cfg), sizeof(ge_transport));return 0;}'
     exe = os.path.join(REPO, "tests", ".probe_sizes")
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(REPO, "include"), "-o", exe], input=src.encode(), check=True)
     try:
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     finally:
         os.remove(exe)
-    assert sizes == [C.sizeof(capi.GloveCfg), C.sizeof(capi.GloveInfo), C.sizeof(capi.Csr), C.sizeof(capi.BcaCfg)]
+    assert sizes == [C.sizeof(capi.GloveCfg), C.sizeof(capi.GloveInfo), C.sizeof(capi.Csr), C.sizeof(capi.BcaCfg), C.sizeof(capi.SyncCfg), C.sizeof(capi.Transport)]
+
+
+def test_jni_glue_compiles_against_a_declared_types_stub():
+    """graph-embeddings_amd/jni/geglove_jni.c is the binding a maintainer adds to the Java host.  No JDK here,
+    so it is compiled -- syntax and types only -- against tests/jni_stub/jni.h, which declares the JNI calls it uses with the
+    specification's signatures: a call with the wrong argument list, a ge_* prototype that moved, a cfg field that no longer
+    exists all fail here.  Every Native method INTEGRATION.md declares has its Java_..._Native_<name> definition."""
+    src = os.path.join(REPO, "graph-embeddings_amd", "jni", "geglove_jni.c")
+    subprocess.run(["gcc", "-fsyntax-only", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(REPO, "tests", "jni_stub"),
+                    "-I", os.path.join(REPO, "include"), src], check=True)
+    glue = set(re.findall(r"Java_org_uu_nl_embedding_hip_Native_(\w+)\(", open(src).read()))
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    native = doc[doc.index("final class Native {"):]
+    native = native[:native.index("\n}\n")]
+    declared = set(re.findall(r"static native [\w\[\]]+\s+(\w+)\(", native))
+    assert declared and declared == glue, (sorted(declared - glue), sorted(glue - declared))
 
 
 def test_argument_errors_come_before_any_device_work():
@@ -190,10 +206,11 @@ def test_measurement_scripts_compile():
     """tools/ and tests/tools/ hold the scripts behind the numbers in DESIGN.md; they need a GPU to run but must at least parse."""
     import glob
     import py_compile
-    scripts = glob.glob(os.path.join(REPO, "tools", "*.py")) + glob.glob(os.path.join(REPO, "tests", "tools", "*.py"))
+    scripts = (glob.glob(os.path.join(REPO, "tools", "*.py")) + glob.glob(os.path.join(REPO, "tools", "r02", "*.py")) +
+               glob.glob(os.path.join(REPO, "tests", "tools", "*.py")))
     assert len(scripts) >= 10
     for path in scripts:
         py_compile.compile(path, doraise=True)
     # the scripts that load the CPU oracle live under tests/ (oracle/ is test infrastructure)
-    for path in glob.glob(os.path.join(REPO, "tools", "*.py")):
+    for path in glob.glob(os.path.join(REPO, "tools", "*.py")) + glob.glob(os.path.join(REPO, "tools", "r02", "*.py")):
         assert "import oracle" not in open(path).read(), path
