@@ -11,7 +11,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libge_oracle.so")
+# GE_ORACLE_LIB: another build of the same sources (oracle/Makefile's `asan` target: -fsanitize=address,undefined)
+_LIB_PATH = os.environ.get("GE_ORACLE_LIB") or os.path.join(_HERE, "libge_oracle.so")
 
 NORM_NONE, NORM_UNITY, NORM_COUNTS = 0, 1, 2
 COST_GLOVE, COST_PGLOVE = 0, 1
@@ -78,7 +79,7 @@ def compare_group(cfg, strings, source, target, source_vertex=None, target_verte
 def build(force=False):
     srcs = [os.path.join(_HERE, f) for f in ("ge_oracle.c", "ge_oracle_sim.c", "ge_oracle.h")]
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["asan"] if _LIB_PATH.endswith("_asan.so") else []))
     return _LIB_PATH
 
 

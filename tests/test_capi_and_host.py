@@ -86,7 +86,7 @@ def test_no_cpu_fallback_without_a_device():
 @pytest.fixture(scope="module")
 def host():
     capi._share_hip_runtime_with_torch()            # libgehost.so pulls in libgeglove.so: same rule as capi.lib()
-    L = C.CDLL(os.path.join(REPO, "graph-embeddings_amd", "lib", "libgehost.so"))
+    L = C.CDLL(os.environ.get("GE_HOST_LIB") or os.path.join(REPO, "graph-embeddings_amd", "lib", "libgehost.so"))
     for f in ("geh_format_11_6E", "geh_java_double", "geh_java_float", "geh_config_summary", "geh_graph_summary"):
         getattr(L, f).restype = C.c_char_p
     L.geh_format_11_6E.argtypes = [C.c_double]; L.geh_java_double.argtypes = [C.c_double]; L.geh_java_float.argtypes = [C.c_float]
