@@ -82,6 +82,50 @@ __global__ __launch_bounds__(256) void k_sync_turn(float *__restrict__ table, in
     }
 }
 
+// The same step for the large tables (cols and the table's row stride multiples of 4, sum rule): one wavefront per row, four
+// elements per lane, 128-bit accesses, no division -- 24 bytes per element for land + take, HBM streaming.
+template <bool LAND, bool TAKE, bool W16>
+__global__ __launch_bounds__(256) void k_sync_turn_rows4(float *__restrict__ table, int64_t t_stride, int32_t cols4, int64_t rows,
+                                                         float *__restrict__ base, void *__restrict__ wire_, void *__restrict__ own_) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t r = wave; r < rows; r += n_waves) {
+        float4 *trow = reinterpret_cast<float4 *>(table + r * t_stride);
+        const int64_t d0 = r * cols4;                                       // index of the row's first group in the dense buffers
+        for (int32_t g = lane; g < cols4; g += 64) {
+            const float4 tv = trow[g];
+            float4 cv = reinterpret_cast<const float4 *>(base)[d0 + g];
+            float res[4] = {tv.x - cv.x, tv.y - cv.y, tv.z - cv.z, tv.w - cv.w};
+            if (LAND) {
+                float w[4], o[4];
+                if (W16) {
+                    const uint2 wv = reinterpret_cast<const uint2 *>(wire_)[d0 + g], ov = reinterpret_cast<const uint2 *>(own_)[d0 + g];
+                    w[0] = bf16_to_f32(wv.x & 0xffffu); w[1] = bf16_to_f32(wv.x >> 16); w[2] = bf16_to_f32(wv.y & 0xffffu); w[3] = bf16_to_f32(wv.y >> 16);
+                    o[0] = bf16_to_f32(ov.x & 0xffffu); o[1] = bf16_to_f32(ov.x >> 16); o[2] = bf16_to_f32(ov.y & 0xffffu); o[3] = bf16_to_f32(ov.y >> 16);
+                } else {
+                    const float4 wv = reinterpret_cast<const float4 *>(wire_)[d0 + g], ov = reinterpret_cast<const float4 *>(own_)[d0 + g];
+                    w[0] = wv.x; w[1] = wv.y; w[2] = wv.z; w[3] = wv.w; o[0] = ov.x; o[1] = ov.y; o[2] = ov.z; o[3] = ov.w;
+                }
+                float c[4] = {cv.x + w[0], cv.y + w[1], cv.z + w[2], cv.w + w[3]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) res[k] -= o[k];
+                trow[g] = make_float4(c[0] + res[0], c[1] + res[1], c[2] + res[2], c[3] + res[3]);
+                reinterpret_cast<float4 *>(base)[d0 + g] = make_float4(c[0], c[1], c[2], c[3]);
+            }
+            if (TAKE) {
+                if (W16) {
+                    const uint32_t h0 = f32_to_bf16_rne(res[0]), h1 = f32_to_bf16_rne(res[1]), h2 = f32_to_bf16_rne(res[2]), h3 = f32_to_bf16_rne(res[3]);
+                    const uint2 hv = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                    reinterpret_cast<uint2 *>(wire_)[d0 + g] = hv; reinterpret_cast<uint2 *>(own_)[d0 + g] = hv;
+                } else {
+                    const float4 rv = make_float4(res[0], res[1], res[2], res[3]);
+                    reinterpret_cast<float4 *>(wire_)[d0 + g] = rv; reinterpret_cast<float4 *>(own_)[d0 + g] = rv;
+                }
+            }
+        }
+    }
+}
+
 // dense <-> strided copies (base initialisation, replicate)
 __global__ void k_gather(const float *table, int64_t t_stride, int32_t cols, int64_t n, float *dense) {
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
@@ -226,6 +270,18 @@ ge_status launch_turn(ge_sync *s, Entry &e, bool land, bool take) {
         s->seed = s->seed * 1664525u + 1013904223u;                    // same sequence on every rank, a new draw per turn
         return ge_exchange_turn_bf16((uint16_t *)s->lay.table, s->lay.hub_rows, s->lay.hub_index, s->lay.vocab_size, s->lay.dim, e.base,
                                      (uint16_t *)e.wire, (uint16_t *)e.own, land, take, s->seed ^ ((uint32_t)s->cfg.rank * 0x9E3779B1u), s->main);
+    }
+    if (!e.mean && e.cols % 4 == 0 && e.t_stride % 4 == 0 && ((uintptr_t)e.table % 16) == 0) {       // the large tables
+        const dim3 g4((unsigned)std::max<int64_t>(1, std::min<int64_t>((e.rows + 3) / 4, (int64_t)s->cus * 16))), b4(256);
+#define GE_TURN4(L, T)                                                                                                              \
+        do {                                                                                                                        \
+            if (e.w16) hipLaunchKernelGGL((k_sync_turn_rows4<L, T, true>), g4, b4, 0, s->main, e.table, e.t_stride, e.cols / 4, e.rows, e.base, e.wire, e.own); \
+            else hipLaunchKernelGGL((k_sync_turn_rows4<L, T, false>), g4, b4, 0, s->main, e.table, e.t_stride, e.cols / 4, e.rows, e.base, e.wire, e.own); \
+        } while (0)
+        if (land && take) GE_TURN4(true, true); else if (land) GE_TURN4(true, false); else GE_TURN4(false, true);
+#undef GE_TURN4
+        GE_HIP(hipGetLastError());
+        return GE_OK;
     }
     const dim3 g(grid_for(e.n, s->cus)), b(256);
 #define GE_TURN(L, T)                                                                                                                        \
