@@ -192,6 +192,15 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
+    # what THIS box's memory system gives a plain device-to-device copy (1 GiB, read + written bytes), right after the timed
+    # region: boxes of the pool differ by 10-15 % in the epoch time of one binary, and this says which kind ran
+    box_copy = None
+    if rank == 0:
+        import ctypes
+        g = ctypes.c_double(0.0)
+        if capi.lib().ge_copy_bandwidth(local_rank, 2 << 30, 5, ctypes.byref(g)) == 0:
+            box_copy = g.value
+
     total_updates = n_local * args.steps
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -248,6 +257,7 @@ def main():
                          "schedule_bytes_per_launch": sched, "schedule_bytes_per_update": sched / max(n_local, 1),
                          "runs_per_launch": info["runs"],
                          "frac_of_measured_copy_ceiling": ach / 6290.0,           # float4 copy, MI355X_MICROARCH.md
+                         "box_copy_GBps": box_copy,                # ge_copy_bandwidth on this box, right after the timed region
                          "kernel_updates_per_s": n_local / avg_kernel_s,
                          # what SURVEY.md 8(d) counts: every update moves both row pairs through HBM (this kernel keeps one in registers)
                          "naive_schedule": {"bytes_per_update": {"read": read_b, "write": write_b},

@@ -28,7 +28,51 @@ ge_status select_device(int device) {
 
 }  // namespace ge
 
+namespace {
+__global__ __launch_bounds__(256) void k_copy16(float4 *__restrict__ dst, const float4 *__restrict__ src, int64_t n4) {
+    // four 16-byte loads in flight per lane before the first store
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+}  // namespace
+
 extern "C" {
+
+// What this device's memory system gives a plain 16-byte-per-lane copy (bytes read + bytes written per second): the practical
+// ceiling a streaming kernel is measured against (MI355X_MICROARCH.md: 6.29 TB/s), taken on the box the bench runs on.
+ge_status ge_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, double *gbps) {
+    if (!gbps || bytes < (1 << 20) || reps < 1) return ge::fail(GE_ERR_ARG, "ge_copy_bandwidth: need >= 1 MiB, >= 1 repetition and an output");
+    ge_status st = ge::select_device(device);
+    if (st != GE_OK) return st;
+    float4 *a = nullptr, *b = nullptr;
+    const int64_t n4 = bytes / 16;
+    GE_HIP(hipMalloc((void **)&a, (size_t)n4 * 16));
+    hipError_t e = hipMalloc((void **)&b, (size_t)n4 * 16);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (e == hipSuccess) e = hipMemset(a, 1, (size_t)n4 * 16);
+    if (e == hipSuccess) e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    float ms = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_copy16, dim3(256 * 8), dim3(256), 0, 0, b, a, n4);                       // warm-up
+        e = hipEventRecord(e0, 0);
+        for (int r = 0; r < reps && e == hipSuccess; ++r) hipLaunchKernelGGL(k_copy16, dim3(256 * 8), dim3(256), 0, 0, b, a, n4);
+        if (e == hipSuccess) e = hipEventRecord(e1, 0);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(a); if (b) (void)hipFree(b);
+    if (e != hipSuccess) return ge::fail(GE_ERR_HIP, "ge_copy_bandwidth: %s", hipGetErrorString(e));
+    *gbps = 2.0 * (double)n4 * 16.0 * reps / ((double)ms * 1e-3) / 1e9;
+    return GE_OK;
+}
 
 const char *ge_last_error(void) { return ge::last_error_buf(); }
 

@@ -34,7 +34,7 @@ SYMBOLS = (
     "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn_bf16", "ge_glove_context_layout",
     "ge_local_group_create", "ge_local_group_destroy", "ge_rccl_unique_id", "ge_rccl_selftest", "ge_sync_cfg_size", "ge_sync_create", "ge_sync_begin", "ge_sync_finish", "ge_sync_turn", "ge_sync_sync",
     "ge_sync_replicate", "ge_sync_allreduce_f64", "ge_sync_destroy",
-    "ge_sim_cfg_default", "ge_sim_cfg_size", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_bca_cfg_size", "ge_device_count",
+    "ge_sim_cfg_default", "ge_sim_cfg_size", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_copy_bandwidth", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_bca_cfg_size", "ge_device_count",
 )
 
 
@@ -175,6 +175,7 @@ def lib():
     if L.ge_sync_cfg_size() != C.sizeof(SyncCfg):
         raise ImportError("libgeglove.so was built from another revision of include/geglove.h (ge_sync_cfg is %d bytes there, %d here)"
                           % (L.ge_sync_cfg_size(), C.sizeof(SyncCfg)))
+    L.ge_copy_bandwidth.argtypes = [C.c_int32, C.c_int64, C.c_int32, f64p]
     L.ge_last_error.argtypes = []; L.ge_last_error.restype = C.c_char_p
     L.ge_version.argtypes = []; L.ge_version.restype = C.c_char_p
     L.ge_device_count.argtypes = []; L.ge_device_count.restype = C.c_int32

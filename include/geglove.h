@@ -425,6 +425,9 @@ const char *ge_version(void);
  * run instead of letting ge_glove_cfg_default write past its struct. */
 int32_t ge_glove_cfg_size(void);
 int32_t ge_bca_cfg_size(void);
+/* Diagnostic: the rate (GB/s, bytes read + written) of a plain 16-byte-per-lane device-to-device copy of `bytes` on this
+ * device -- the practical ceiling bench.py prints beside a kernel's own rate (the boxes of a pool differ). */
+ge_status ge_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, double *gbps);
 /* Number of visible HIP devices that are gfx950; <0 on HIP error. Does not compute. */
 int32_t ge_device_count(void);
 

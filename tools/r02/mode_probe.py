@@ -47,6 +47,20 @@ for r in range(recreate):
             run["chase_idle_" + name] = round(ch.chase(ptr, V, 816, 20000, 1), 1)            # one wave: latency of a random row, TLB miss included
             run["chase_small_" + name] = round(ch.chase(ptr, 20000, 816, 20000, 1), 1)      # 16 MB: translations cached
             run["chase_load_" + name] = round(ch.chase(ptr, V, 816, 4000, 4096), 1)         # 4096 waves at once
+    if os.environ.get("GE_PROBE_XCD"):
+        import ctypes as C
+        ch = C.CDLL(os.path.join(ROOT, "tools", "micro", "libchase.so"))
+        ch.xcd_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        hipl = C.CDLL(None)
+        buf = C.c_void_p()
+        hipl.hipMalloc(C.byref(buf), C.c_size_t(256 * (16 << 20)))
+        hipl.hipMemset(buf, 1, C.c_size_t(256 * (16 << 20)))
+        g = (C.c_double * 8)(); mm = (C.c_double * 3)()
+        ch.xcd_stream(buf, 256, 1, g, mm)
+        ch.xcd_stream(buf, 256, 4, g, mm)
+        run["xcd_GBps"] = [round(x, 1) for x in g]; run["xcd_total_TBps"] = round(256 * 4 * (16 << 20) / (mm[2] * 1e-3) / 1e12, 3)
+        run["xcd_ticks_min_max"] = [mm[0], mm[1]]
+        hipl.hipFree(buf)
     out["runs"].append(run)
     opt.close()
 print(json.dumps(out), flush=True)
