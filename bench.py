@@ -271,6 +271,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, V, D, I, J, X, xmax)
         print(json.dumps(out), flush=True)
+    if sync is not None:
+        sync.close()                  # the RCCL communicator goes before the handle it serves
     opt.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -30,7 +30,7 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 }
 
 template <bool LAND, bool TAKE>
-__global__ __launch_bounds__(256) void k_exchange_turn_bf16(uint16_t *__restrict__ table, float *__restrict__ hub_rows,
+__global__ __launch_bounds__(256) void k_exchange_turn_bf16(uint16_t *__restrict__ table, int64_t stride4, float *__restrict__ hub_rows,
                                                             const int32_t *__restrict__ hub_index, int32_t D4, int64_t n4,
                                                             float *__restrict__ base, uint16_t *__restrict__ wire, uint16_t *__restrict__ own,
                                                             uint32_t seed) {
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_exchange_turn_bf16(uint16_t *__restrict
             const float4 tv = reinterpret_cast<const float4 *>(hub_rows)[(int64_t)hub * D4 + c4];
             t[0] = tv.x; t[1] = tv.y; t[2] = tv.z; t[3] = tv.w;
         } else {
-            const uint2 tv = reinterpret_cast<const uint2 *>(table)[q];
+            const uint2 tv = reinterpret_cast<const uint2 *>(table)[(int64_t)v * stride4 + c4];
             t[0] = bf16_to_f32(tv.x & 0xffffu); t[1] = bf16_to_f32(tv.x >> 16); t[2] = bf16_to_f32(tv.y & 0xffffu); t[3] = bf16_to_f32(tv.y >> 16);
         }
         const float4 bv = reinterpret_cast<const float4 *>(base)[q];
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_exchange_turn_bf16(uint16_t *__restrict
         }
         if (LAND) {
             if (hub >= 0) reinterpret_cast<float4 *>(hub_rows)[(int64_t)hub * D4 + c4] = make_float4(t[0], t[1], t[2], t[3]);
-            else reinterpret_cast<uint2 *>(table)[q] = make_uint2(t16[0] | (t16[1] << 16), t16[2] | (t16[3] << 16));
+            else reinterpret_cast<uint2 *>(table)[(int64_t)v * stride4 + c4] = make_uint2(t16[0] | (t16[1] << 16), t16[2] | (t16[3] << 16));
         }
         reinterpret_cast<float4 *>(base)[q] = make_float4(b[0], b[1], b[2], b[3]);
         if (TAKE) {
@@ -86,10 +86,11 @@ __global__ __launch_bounds__(256) void k_exchange_turn_bf16(uint16_t *__restrict
 
 }  // namespace
 
-extern "C" ge_status ge_exchange_turn_bf16(uint16_t *table, float *hub_rows, const int32_t *hub_index, int32_t vocab_size, int32_t dim,
+extern "C" ge_status ge_exchange_turn_bf16(uint16_t *table, int32_t row_stride, float *hub_rows, const int32_t *hub_index, int32_t vocab_size, int32_t dim,
                                            float *base, uint16_t *wire, uint16_t *own, int32_t land, int32_t take, uint32_t seed, void *stream) {
     if (!table || !base || !hub_index || !wire || !own) return ge::fail(GE_ERR_ARG, "ge_exchange_turn_bf16: null pointer");
     if (vocab_size < 0 || dim <= 0 || dim % 4 != 0) return ge::fail(GE_ERR_ARG, "ge_exchange_turn_bf16: dim must be a positive multiple of 4");
+    if (row_stride < dim || row_stride % 4 != 0) return ge::fail(GE_ERR_ARG, "ge_exchange_turn_bf16: row_stride must be a multiple of 4 and >= dim");
     if (((uintptr_t)table | (uintptr_t)wire | (uintptr_t)own) % 8 || ((uintptr_t)hub_rows | (uintptr_t)base) % 16)
         return ge::fail(GE_ERR_ARG, "ge_exchange_turn_bf16: misaligned buffer");
     if ((!land && !take) || vocab_size == 0) return GE_OK;
@@ -99,9 +100,9 @@ extern "C" ge_status ge_exchange_turn_bf16(uint16_t *table, float *hub_rows, con
     const int64_t n4 = (int64_t)vocab_size * (dim / 4);
     const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n4 + 255) / 256, (int64_t)cus * 8));
     hipStream_t s = (hipStream_t)stream;
-    if (land && take)  hipLaunchKernelGGL((k_exchange_turn_bf16<true, true>),  dim3(blocks), dim3(256), 0, s, table, hub_rows, hub_index, dim / 4, n4, base, wire, own, seed);
-    else if (land)     hipLaunchKernelGGL((k_exchange_turn_bf16<true, false>), dim3(blocks), dim3(256), 0, s, table, hub_rows, hub_index, dim / 4, n4, base, wire, own, seed);
-    else               hipLaunchKernelGGL((k_exchange_turn_bf16<false, true>), dim3(blocks), dim3(256), 0, s, table, hub_rows, hub_index, dim / 4, n4, base, wire, own, seed);
+    if (land && take)  hipLaunchKernelGGL((k_exchange_turn_bf16<true, true>), dim3(blocks), dim3(256), 0, s, table, (int64_t)(row_stride / 4), hub_rows, hub_index, dim / 4, n4, base, wire, own, seed);
+    else if (land)     hipLaunchKernelGGL((k_exchange_turn_bf16<true, false>), dim3(blocks), dim3(256), 0, s, table, (int64_t)(row_stride / 4), hub_rows, hub_index, dim / 4, n4, base, wire, own, seed);
+    else               hipLaunchKernelGGL((k_exchange_turn_bf16<false, true>), dim3(blocks), dim3(256), 0, s, table, (int64_t)(row_stride / 4), hub_rows, hub_index, dim / 4, n4, base, wire, own, seed);
     GE_HIP(hipGetLastError());
     return GE_OK;
 }

@@ -58,6 +58,7 @@ struct GloveParams {
     int32_t D;
     int32_t DS;            // row stride of the fp32 row tables in floats (>= RW; a multiple of RW when a row and its accumulator rows interleave)
     int32_t RW;            // row width in floats: D, or D + 4 when a row carries its bias at [D] (fat rows, Hogwild)
+    int32_t ES;            // bf16 rows: bf16 elements between consecutive embedding rows (D, or 2 * DS when a row shares a record with its accumulator row)
     int32_t cost_kind;
     float lr;
     int32_t order_mode;
@@ -184,18 +185,20 @@ __global__ void k_fat_scatter(float *fat, int64_t rows, int32_t DS, int32_t col0
 }
 
 // bf16 embeddings (BASELINE config C5): storage conversions.  Round-to-nearest-even on the way in (init, set_state).
-__global__ void k_f32_to_bf16(const float *src, uint16_t *dst, int64_t n) {
+// dense fp32 [rows x D] <-> bf16 rows `es` elements apart
+__global__ void k_f32_to_bf16(const float *src, uint16_t *dst, int64_t n, int32_t D, int64_t es) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         const uint32_t u = __builtin_bit_cast(uint32_t, src[i]);
-        dst[i] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+        const int64_t r = i / D;
+        dst[r * es + (i - r * D)] = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
     }
 }
-__global__ void k_bf16_to_f32(const uint16_t *src, float *dst, int64_t n) {
+__global__ void k_bf16_to_f32(const uint16_t *src, float *dst, int64_t n, int32_t D, int64_t es) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) dst[i] = __builtin_bit_cast(float, (uint32_t)src[i] << 16);
+    for (; i < n; i += stride) { const int64_t r = i / D; dst[i] = __builtin_bit_cast(float, (uint32_t)src[r * es + (i - r * D)] << 16); }
 }
 // hub rows live in the fp32 master table: dir 0 = full[col] -> hub32[idx], dir 1 = hub32[idx] -> full[col]
 __global__ void k_hub_rows(float *full, float *hub32, const int32_t *hub_index, int32_t V, int32_t D, int dir) {
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
     uint32_t sr_state = 0x9E3779B9u * (uint32_t)(threadIdx.x + 1) + (uint32_t)blockIdx.x * 0x85EBCA6Bu + p.bij_key[0];
     // embedding-row access: fp32 build = plain 16-byte vectors; bf16 build = 8 bytes widened / narrowed here
     auto emb_rsrc = [&](float *base, int64_t id) {
-        if constexpr (EMB16) return make_rsrc(reinterpret_cast<uint16_t *>(base) + id * p.D, (uint32_t)p.D * 2u);
+        if constexpr (EMB16) return make_rsrc(reinterpret_cast<uint16_t *>(base) + id * p.ES, (uint32_t)p.D * 2u);
         else return make_rsrc(base + id * p.DS, (uint32_t)p.RW * 4u);
     };
     auto emb_load = [&](__amdgpu_buffer_rsrc_t rs, int q) -> VT {
@@ -879,6 +882,7 @@ struct ge_glove {
     bool fat = false;                 // fp32 Hogwild: a row is D + 4 floats with its bias at [D]; tab[*BIAS] are null
     int32_t rw = 0;                   // row width of the fp32 row tables in floats (D, or D + 4 when fat)
     int32_t ds = 0;                   // row stride of the fp32 row tables in floats (rw, or a multiple when the tables interleave)
+    int32_t es = 0;                   // bf16 rows: bf16 elements between consecutive embedding rows (dim, or 2 * ds inside records)
     float *hub32 = nullptr;           // bf16 build: fp32 master rows of the hub columns
     int32_t *dhub_index = nullptr;
     std::vector<int32_t> host_hub_index;
@@ -918,12 +922,12 @@ void fill_params(const ge_glove *h, GloveParams &p, int32_t iteration) {
     }
     // focus-side tables hold rows [row_begin,row_end): rebase so that kernels index by global row id
     const int64_t off = h->cfg.row_begin;
-    if (h->emb16) p.focus = reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(p.focus) - off * h->cfg.dim);
+    if (h->emb16) p.focus = reinterpret_cast<float *>(reinterpret_cast<uint16_t *>(p.focus) - off * h->es);
     else p.focus -= off * h->ds;
     p.gsf -= off * h->ds;
     if (!h->fat) { p.fbias -= off; p.gsfb -= off; }
     if (p.m2f) { p.m2f -= off * h->ds; if (!h->fat) p.m2fb -= off; }
-    p.DS = h->ds; p.RW = h->rw;
+    p.DS = h->ds; p.RW = h->rw; p.ES = h->es;
     p.I = h->dI; p.J = h->dJ; p.X = h->dX; p.perm = h->dperm;
     p.L = h->blocked ? h->lay.L : h->dL; p.W = h->blocked ? h->lay.W : h->dW;
     p.cost_out = h->dcost;
@@ -1014,9 +1018,12 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     const int32_t V = cfg->vocab_size, D = cfg->dim;
     const int64_t N = cfg->nnz;
     const bool moments = cfg->opt != GE_OPT_ADAGRAD;      // Adam / AMSGrad keep M2* next to M1*
-    const bool interleave = cfg->mode == GE_MODE_HOGWILD && !emb16 && (cfg->layout_flags & GE_LAYOUT_SEPARATE_TABLES) == 0;
+    const bool interleave = cfg->mode == GE_MODE_HOGWILD && (cfg->layout_flags & GE_LAYOUT_SEPARATE_TABLES) == 0;
     h->rw = h->fat ? D + 4 : D;
     h->ds = h->rw * (interleave ? (moments ? 3 : 2) : 1);
+    // bf16 rows in records: [bf16 row, padded to 16 bytes | fp32 accumulator row]; e16 = bf16 elements of the padded row
+    const int32_t e16 = (D + 7) / 8 * 8;
+    if (emb16) { h->ds = interleave ? e16 / 2 + D : D; h->es = interleave ? 2 * h->ds : D; }
 
     // every failure below frees what the handle owns so far (ge_glove_destroy walks h->owned)
 #define GE_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ge_status _s = ge::fail(_e == hipErrorOutOfMemory ? GE_ERR_OOM : GE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); ge_glove_destroy(h); return _s; } } while (0)
@@ -1042,7 +1049,8 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
             if (interleave) {
                 float *blk = nullptr;
                 GE_TRY(h->alloc(&blk, nr * (size_t)h->ds));
-                for (int a = 0; a < n_aux; ++a) h->tab[ROWT[side][a]] = blk + (size_t)a * h->rw;
+                if (emb16) { h->tab[ROWT[side][0]] = blk; h->tab[ROWT[side][1]] = blk + e16 / 2; }     // the bf16 row leads its record
+                else for (int a = 0; a < n_aux; ++a) h->tab[ROWT[side][a]] = blk + (size_t)a * h->rw;
             } else {
                 for (int a = 0; a < n_aux; ++a) {
                     if (a == 0 && emb16) { uint16_t *t16 = nullptr; GE_TRY(h->alloc(&t16, nr * (size_t)D)); h->tab[ROWT[side][0]] = reinterpret_cast<float *>(t16); }
@@ -1152,7 +1160,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
         GE_TRY(h->alloc(&h->hub32, (size_t)std::max<int64_t>((int64_t)h->n_hub * D, 1)));
     }
     {
-        const int64_t stride = emb16 ? D : h->ds;
+        const int64_t stride = emb16 ? h->es : h->ds;
         const int32_t bias_col = h->fat ? D : -1;
         void *foc = h->tab[GE_STATE_FOCUS], *ctx = h->tab[GE_STATE_CONTEXT];
         auto launch = [&](void *f, void *c, int32_t row0, int32_t nrows) {
@@ -1269,7 +1277,7 @@ static ge_status materialize_f32(ge_glove *h, int which, float **out) {
         return GE_OK;
     }
     hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 8192)), dim3(256), 0, h->stream,
-                       reinterpret_cast<const uint16_t *>(h->tab[which]), d, n);
+                       reinterpret_cast<const uint16_t *>(h->tab[which]), d, n, h->cfg.dim, (int64_t)h->es);
     if (which == GE_STATE_CONTEXT && h->n_hub > 0)
         hipLaunchKernelGGL(k_hub_rows, dim3((unsigned)h->cfg.vocab_size), dim3(64), 0, h->stream, d, h->hub32, h->dhub_index, h->cfg.vocab_size, h->cfg.dim, 1);
     hipError_t e = hipGetLastError();
@@ -1361,7 +1369,7 @@ ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_
             if (which == GE_STATE_CONTEXT && h->n_hub > 0)
                 hipLaunchKernelGGL(k_hub_rows, dim3((unsigned)h->cfg.vocab_size), dim3(64), 0, h->stream, d, h->hub32, h->dhub_index, h->cfg.vocab_size, h->cfg.dim, 0);
             hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)std::min<int64_t>((count + 255) / 256, 8192)), dim3(256), 0, h->stream,
-                               d, reinterpret_cast<uint16_t *>(h->tab[which]), count);
+                               d, reinterpret_cast<uint16_t *>(h->tab[which]), count, h->cfg.dim, (int64_t)h->es);
             e = hipStreamSynchronize(h->stream);
         }
         (void)hipFree(d);
@@ -1399,8 +1407,9 @@ ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out) {
     out->hub_index = h->emb16 ? h->dhub_index : nullptr;
     out->n_hub = h->emb16 ? h->n_hub : 0;
     out->vocab_size = h->cfg.vocab_size; out->dim = h->cfg.dim;
-    out->row_stride = h->emb16 ? h->cfg.dim : h->ds;
+    out->row_stride = h->emb16 ? h->es : h->ds;
     out->accum = h->tab[GE_STATE_GSQ_CONTEXT];
+    out->accum_stride = h->ds;
     return GE_OK;
 }
 

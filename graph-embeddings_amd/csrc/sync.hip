@@ -136,11 +136,11 @@ __global__ void k_scatter2(float *table, int64_t t_stride, int32_t cols, int64_t
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) { const int64_t r = k / cols; const float v = dense[k]; table[r * t_stride + (k - r * cols)] = v; base[k] = v; }
 }
 // bf16 context rows: current values widened (hub rows from their fp32 masters)
-__global__ void k_bf16_values(const uint16_t *table, const float *hub_rows, const int32_t *hub_index, int32_t D, int64_t n, float *out) {
+__global__ void k_bf16_values(const uint16_t *table, int64_t stride, const float *hub_rows, const int32_t *hub_index, int32_t D, int64_t n, float *out) {
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {
         const int64_t v = k / D; const int32_t h = hub_index[v];
-        out[k] = h >= 0 ? hub_rows[(int64_t)h * D + (k - v * D)] : bf16_to_f32(table[k]);
+        out[k] = h >= 0 ? hub_rows[(int64_t)h * D + (k - v * D)] : bf16_to_f32(table[v * stride + (k - v * D)]);
     }
 }
 
@@ -268,7 +268,7 @@ ge_status launch_turn(ge_sync *s, Entry &e, bool land, bool take) {
     if (!land && !take) return GE_OK;
     if (e.bf16_rows) {
         s->seed = s->seed * 1664525u + 1013904223u;                    // same sequence on every rank, a new draw per turn
-        return ge_exchange_turn_bf16((uint16_t *)s->lay.table, s->lay.hub_rows, s->lay.hub_index, s->lay.vocab_size, s->lay.dim, e.base,
+        return ge_exchange_turn_bf16((uint16_t *)s->lay.table, s->lay.row_stride, s->lay.hub_rows, s->lay.hub_index, s->lay.vocab_size, s->lay.dim, e.base,
                                      (uint16_t *)e.wire, (uint16_t *)e.own, land, take, s->seed ^ ((uint32_t)s->cfg.rank * 0x9E3779B1u), s->main);
     }
     if (!e.mean && e.cols % 4 == 0 && e.t_stride % 4 == 0 && ((uintptr_t)e.table % 16) == 0) {       // the large tables
@@ -470,8 +470,8 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
         s->ent.back().bf16_rows = true;
     } else add("context rows", (float *)s->lay.table, s->lay.row_stride, D, false, false, w16);
     add("cBias", bias_in_row ? (float *)s->lay.table + D : (float *)p_cb, bias_in_row ? s->lay.row_stride : 1, 1, true, false, false);
-    add("gradSqContext", s->lay.accum, s->lay.dtype == GE_DTYPE_BF16 ? D : s->lay.row_stride, D, false, true, w16);
-    add("gradSqCBias", bias_in_row ? s->lay.accum + D : (float *)p_gcb, bias_in_row ? s->lay.row_stride : 1, 1, false, true, false);
+    add("gradSqContext", s->lay.accum, s->lay.accum_stride, D, false, true, w16);
+    add("gradSqCBias", bias_in_row ? s->lay.accum + D : (float *)p_gcb, bias_in_row ? s->lay.accum_stride : 1, 1, false, true, false);
     if (cfg->world > 1) {
         for (Entry &e : s->ent) {
             GE_TRYS(s->alloc(&e.base, (size_t)e.n));
@@ -479,7 +479,7 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
             GE_TRYS(s->alloc((char **)&e.wire, (size_t)e.n * wb)); GE_TRYS(s->alloc((char **)&e.own, (size_t)e.n * wb));
             if (e.mean) GE_TRYS(s->alloc(&e.cnt, (size_t)e.n));
             // the base is the table NOW, before any local pass
-            if (e.bf16_rows) hipLaunchKernelGGL(k_bf16_values, dim3(grid_for(e.n, s->cus)), dim3(256), 0, s->main, (const uint16_t *)s->lay.table, s->lay.hub_rows,
+            if (e.bf16_rows) hipLaunchKernelGGL(k_bf16_values, dim3(grid_for(e.n, s->cus)), dim3(256), 0, s->main, (const uint16_t *)s->lay.table, (int64_t)s->lay.row_stride, s->lay.hub_rows,
                                                 s->lay.hub_index, D, e.n, e.base);
             else hipLaunchKernelGGL(k_gather, dim3(grid_for(e.n, s->cus)), dim3(256), 0, s->main, e.table, e.t_stride, e.cols, e.n, e.base);
         }

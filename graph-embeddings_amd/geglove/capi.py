@@ -80,7 +80,8 @@ class Strings(C.Structure):
 
 class ContextLayout(C.Structure):
     _fields_ = [("table", C.c_void_p), ("dtype", C.c_int32), ("hub_rows", C.c_void_p), ("hub_index", C.c_void_p),
-                ("n_hub", C.c_int32), ("vocab_size", C.c_int32), ("dim", C.c_int32), ("row_stride", C.c_int32), ("accum", C.c_void_p)]
+                ("n_hub", C.c_int32), ("vocab_size", C.c_int32), ("dim", C.c_int32), ("row_stride", C.c_int32), ("accum", C.c_void_p),
+                ("accum_stride", C.c_int32)]
 
 
 TRANSPORT_START = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p))
@@ -159,7 +160,7 @@ def lib():
     L.ge_sim_pairs_get.argtypes = [vp, i64p, C.POINTER(i32p), C.POINTER(i32p), C.POINTER(f32p)]
     L.ge_sim_pairs_destroy.argtypes = [vp]; L.ge_sim_pairs_destroy.restype = None
     L.ge_glove_context_layout.argtypes = [vp, C.POINTER(ContextLayout)]
-    L.ge_exchange_turn_bf16.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_uint32, vp]
+    L.ge_exchange_turn_bf16.argtypes = [vp, C.c_int32, vp, vp, C.c_int32, C.c_int32, vp, vp, vp, C.c_int32, C.c_int32, C.c_uint32, vp]
     L.ge_rccl_unique_id.argtypes = [vp]
     L.ge_local_group_create.argtypes = [C.c_int32, C.POINTER(vp)]
     L.ge_local_group_destroy.argtypes = [vp]; L.ge_local_group_destroy.restype = None

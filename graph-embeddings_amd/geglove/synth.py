@@ -169,3 +169,19 @@ def synthetic_coo_shard(V_total, row_range, n_local, seed=0xC0FFEE):
     X = np.clip(X, 1.0001e-4, 0.2).astype(np.float32)
     X[I == J] = np.float32(0.2)
     return I, J, X, float(np.float32(0.2))
+
+
+def lattice_graph(V=2048, stride=16, reach=10, every=3):
+    """Vertices numbered so that neighbours are regular multiples apart (what sequentially numbered entity types give): vertex v
+    (every `every`-th one) points at v + stride, v + 2 stride, ..., v + reach * stride (mod V) and at v + 1.  The keys of a row then
+    pile up in single java.util.HashMap bins: rows meet the early resize of treeifyBin and, from 64 buckets on, tree bins."""
+    src, dst = [], []
+    for v in range(0, V, every):
+        for k in range(1, reach + 1):
+            src.append(v); dst.append((v + stride * k) % V)
+        src.append(v); dst.append((v + 1) % V)
+    src = np.array(src, np.int64); dst = np.array(dst, np.int64)
+    keep = src != dst
+    pairs = np.unique(np.stack([src[keep], dst[keep]], 1), axis=0)
+    out, inn = edges_to_csr(V, pairs[:, 0], pairs[:, 1], np.ones(len(pairs), np.float32))
+    return dict(V=V, out=out, inn=inn)

@@ -337,10 +337,12 @@ typedef struct {
     float         *hub_rows;     /* [n_hub x dim] */
     const int32_t *hub_index;    /* [vocab_size], device memory */
     int32_t        n_hub, vocab_size, dim;
-    int32_t        row_stride;   /* floats between consecutive rows of `table` and `accum`.  GE_MODE_HOGWILD fp32 handles keep FAT
-                                    rows: row_stride = dim + 4, element [dim] of a row is its bias (cBias in `table`, gradSqCBias /
-                                    M1 in `accum`), the rest zero padding; otherwise row_stride = dim and biases are separate */
-    float         *accum;        /* gradSqContext (Adam/AMSGrad: M1context), same row layout as `table`; fp32 always */
+    int32_t        row_stride;   /* elements of `table`'s dtype between consecutive rows of `table`.  fp32 GE_MODE_HOGWILD handles keep
+                                    FAT rows (width dim + 4, a row's bias at [dim]) inside records [row | accumulator row]: row_stride =
+                                    2 (dim + 4) floats; bf16 rows lead records [bf16 row padded to 16 B | fp32 accumulator row]:
+                                    row_stride = that record in bf16 elements; GE_LAYOUT_SEPARATE_TABLES: the row width itself */
+    float         *accum;        /* gradSqContext (Adam/AMSGrad: M1context); fp32 always; fat like `table` when that is fp32 */
+    int32_t        accum_stride; /* floats between consecutive rows of `accum` (its bias accumulator at [dim] when fat)             */
 } ge_context_layout;
 ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out);
 
@@ -350,10 +352,11 @@ ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out);
  *               this rank's part of it: the difference is what the others sent);
  *   take != 0:  d = bf16(row value - base) (before landing); wire = own = d; base += d.
  * A row's value lives in hub_rows[hub_index[v]] (fp32 master) when the column is a hub on this rank, else in the bf16 table.
+ * The table's rows are `row_stride` bf16 elements apart (a multiple of 4; ge_context_layout.row_stride).
  * `base` is float[vocab_size*dim] for EVERY row (start: the row values widened), wire / own are bf16[vocab_size*dim].  Landed
  * ordinary rows are re-narrowed with stochastic rounding drawn from `seed` (a new one every turn); that rounding is part of
  * value - base and is fed back with the next delta. */
-ge_status ge_exchange_turn_bf16(uint16_t *table, float *hub_rows, const int32_t *hub_index, int32_t vocab_size, int32_t dim,
+ge_status ge_exchange_turn_bf16(uint16_t *table, int32_t row_stride, float *hub_rows, const int32_t *hub_index, int32_t vocab_size, int32_t dim,
                                 float *base, uint16_t *wire, uint16_t *own, int32_t land, int32_t take, uint32_t seed, void *stream);
 
 /* ------------------------------------------------------------------------------------------ */

@@ -36,6 +36,14 @@ def main():
             out["train_%s_%d_perm" % (method, D)] = m.perm.copy()
     np.savez_compressed(os.path.join(HERE, "dblp_like_60_90_4.npz"), **out)
     print("wrote", os.path.join(HERE, "dblp_like_60_90_4.npz"), "keys:", len(out))
+    # a regular-id lattice: rows whose keys share java.util.HashMap bins (early treeifyBin resize, tree bins from 64 buckets on)
+    g = synth.lattice_graph(2048, 16, 10, 3)
+    out = {}
+    for name, directed, norm in (("dir_none", True, O.NORM_NONE), ("und_unity", False, O.NORM_UNITY), ("dir_counts", True, O.NORM_COUNTS)):
+        c = O.bca_build(g["V"], g["out"], g["inn"], 0.1, 1e-4, directed, norm)
+        out.update({"bca_%s_I" % name: c["I"], "bca_%s_J" % name: c["J"], "bca_%s_X" % name: c["X"], "bca_%s_max" % name: np.float64(c["max"])})
+    np.savez_compressed(os.path.join(HERE, "lattice_2048_16.npz"), **out)
+    print("wrote", os.path.join(HERE, "lattice_2048_16.npz"), "nnz:", {k: len(v) for k, v in out.items() if k.endswith("_J")})
 
 
 if __name__ == "__main__":

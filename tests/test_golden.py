@@ -62,3 +62,29 @@ def test_device_matches_golden_training(gpu, method, D):
     ref = GOLD["train_%s_%d_vec" % (method, D)]
     assert np.max(np.abs(got - ref)) <= 1e-4          # north-star tolerance
     np.testing.assert_array_equal(got, ref)           # in fact bit-exact
+
+
+# ---- a regular-id lattice: rows that meet java.util.HashMap's treeifyBin (early resize, tree bins) --------------------------
+LAT = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lattice_2048_16.npz"))
+GL = synth.lattice_graph(2048, 16, 10, 3)
+LAT_CASES = [("dir_none", True, "none"), ("und_unity", False, "unity"), ("dir_counts", True, "counts")]
+
+
+@pytest.mark.parametrize("name,directed,norm", LAT_CASES)
+def test_oracle_reproduces_golden_lattice(name, directed, norm):
+    c = O.bca_build(GL["V"], GL["out"], GL["inn"], 0.1, 1e-4, directed, NORM[norm])
+    np.testing.assert_array_equal(c["J"], LAT["bca_%s_J" % name])
+    assert np.array_equal(c["X"].view(np.uint32), LAT["bca_%s_X" % name].view(np.uint32))
+    assert c["max"] == float(LAT["bca_%s_max" % name])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,directed,norm", LAT_CASES)
+def test_device_matches_golden_lattice(gpu, name, directed, norm):
+    cfg = make_config(8)
+    cfg.bca = {"alpha": 0.1, "epsilon": 1e-4, "directed": directed, "normalize": norm}
+    d = geglove.BookmarkColoring(GL, cfg)
+    np.testing.assert_array_equal(d.I, LAT["bca_%s_I" % name])
+    np.testing.assert_array_equal(d.J, LAT["bca_%s_J" % name])
+    assert np.array_equal(d.X.view(np.uint32), LAT["bca_%s_X" % name].view(np.uint32))
+    assert d.max() == float(LAT["bca_%s_max" % name])

@@ -218,9 +218,11 @@ def _np_mix32(x):
     return x
 
 
+@pytest.mark.parametrize("pad", [0, 20])
 @pytest.mark.parametrize("land,take", [(0, 1), (1, 0), (1, 1)])
-def test_exchange_turn_bf16_matches_a_numpy_model(gpu, land, take):
-    """ge_exchange_turn_bf16 on a table whose rows 3, 10 and 11 are hubs (fp32 master rows) against the same arithmetic in numpy."""
+def test_exchange_turn_bf16_matches_a_numpy_model(gpu, land, take, pad):
+    """ge_exchange_turn_bf16 on a table whose rows 3, 10 and 11 are hubs (fp32 master rows) against the same arithmetic in numpy;
+    pad > 0: the rows sit `dim + pad` elements apart (records), the elements between them must stay untouched."""
     from geglove import capi
     rng = np.random.default_rng(land * 2 + take)
     V, D, seed = 37, 12, 0xABCDEF
@@ -236,11 +238,16 @@ def test_exchange_turn_bf16_matches_a_numpy_model(gpu, land, take):
     w16[5 * D:6 * D] = o16[5 * D:6 * D]                                  # row 5: nobody else moved it
     dev = torch.device("cuda", 0)
     as_dev = lambda a: torch.from_numpy(a.view(np.int16) if a.dtype == np.uint16 else a).to(dev)
-    d_t, d_b, d_w, d_o, d_hub, d_idx = map(as_dev, (t16.copy(), b.copy(), w16.copy(), o16.copy(), hub.copy(), hub_index))
-    capi.check(capi.lib().ge_exchange_turn_bf16(d_t.data_ptr(), d_hub.data_ptr(), d_idx.data_ptr(), V, D, d_b.data_ptr(),
+    S = D + pad
+    wide = np.full((V, S), 0x7777, np.uint16); wide[:, :D] = t16.reshape(V, D)                  # the table as stored: rows S elements apart
+    d_t, d_b, d_w, d_o, d_hub, d_idx = map(as_dev, (wide.reshape(-1).copy(), b.copy(), w16.copy(), o16.copy(), hub.copy(), hub_index))
+    capi.check(capi.lib().ge_exchange_turn_bf16(d_t.data_ptr(), S, d_hub.data_ptr(), d_idx.data_ptr(), V, D, d_b.data_ptr(),
                                                 d_w.data_ptr(), d_o.data_ptr(), land, take, seed, None))
     torch.cuda.synchronize()
     back = lambda x: x.cpu().numpy().view(np.uint16) if x.dtype == torch.int16 else x.cpu().numpy()
+    stored = back(d_t).reshape(V, S)
+    assert np.all(stored[:, D:] == 0x7777)                                                      # nothing outside the rows was touched
+    d_t = torch.from_numpy(stored[:, :D].reshape(-1).copy().view(np.int16))
     # ---- model ----
     d = (t - b).astype(np.float32)
     r = (_np_bf16_to_f32(w16) - _np_bf16_to_f32(o16)).astype(np.float32)
