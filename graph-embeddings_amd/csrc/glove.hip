@@ -1,17 +1,17 @@
 // glove.hip -- GloVe / pGloVe AdaGrad trainer for MI355X (gfx950): kernels + C ABI.
 //
 // Reference semantics (J/ = src/main/java/org/uu/nl/embedding/ of Phaken/graph-embeddings):
-//   Optimizer ctor           J/opt/Optimizer.java:34-64     -> k_init_java / k_fill
-//   Adagrad.createJob        J/opt/grad/Adagrad.java:42-98  -> k_adagrad_exact (bit-exact) / k_adagrad_hogwild
+//   Optimizer ctor           J/opt/Optimizer.java:34-64     -> k_init_java / k_fill_rows
+//   Adagrad.createJob        J/opt/grad/Adagrad.java:42-98  -> k_adagrad_exact (bit-exact) / k_adagrad_runs (Hogwild)
 //   GloveCost / PGloveCost   J/opt/GloveCost.java:7-20, J/opt/PGloveCost.java:7-20 -> cost_terms()
 //   Optimizer.extractResult  J/opt/Optimizer.java:129-140   -> k_extract
 //
 // This file is compiled with -ffp-contract=off: the exact kernel must not fuse a*b+c
 // (Java never does); the Hogwild kernel asks for FMAs explicitly where it wants them.
 //
-// Roofline: HBM.  Algorithmic bytes per pair-update (fp32): read 16*D+28, write 16*D+16
-// (two embedding rows, two AdaGrad accumulator rows, four bias/accumulator scalars, one
-// 12-byte (i,j,X) triple); SURVEY.md 8(d), DESIGN.md.  No MFMA: sparse gather + length-D dot.
+// Roofline: HBM.  SURVEY.md 8(d) counts read 16*D+28 / write 16*D+16 bytes per pair-update (both row pairs through HBM);
+// k_adagrad_runs keeps one pair in registers per run and has to move 20 + 4 * row bytes per nonzero + 4 * row bytes per
+// run (ge_glove_info.schedule_bytes).  No MFMA: sparse gather + length-D dot.
 
 #include "ge_common.h"
 #include "ge_javarand.h"

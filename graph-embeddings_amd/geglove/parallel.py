@@ -153,9 +153,27 @@ class ContextSync:
 
 def context_sync_for(optimizer, device, lazy_every=4, wire="bf16", group=None, transport=None):
     """The ContextSync of one rank's handle inside an initialised torch.distributed job: RCCL when the backend is nccl (one
-    GPU per rank), callbacks into torch.distributed otherwise (gloo: ranks that share a GPU)."""
+    GPU per rank), callbacks into torch.distributed otherwise (gloo: ranks that share a GPU).  Should the library's own RCCL
+    communicator fail to come up on ANY rank (the ranks agree through an all-reduce), every rank falls back to the callback
+    transport over the job's own process group -- the same exchange, torch's communicator instead of the library's."""
+    import torch
     import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     if transport is None:
         transport = "rccl" if dist.get_backend(group) == "nccl" else "torch"
-    return ContextSync(optimizer, dist.get_world_size(group), dist.get_rank(group), wire=wire, accum_every=lazy_every,
-                       transport=transport, device=device, group=group)
+    if transport != "rccl" or world == 1:
+        return ContextSync(optimizer, world, rank, wire=wire, accum_every=lazy_every, transport=transport, device=device, group=group)
+    sync, err = None, None
+    try:
+        sync = ContextSync(optimizer, world, rank, wire=wire, accum_every=lazy_every, transport="rccl", device=device, group=group)
+    except capi.GeError as e:
+        err = e
+    ok = torch.tensor([0.0 if sync is None else 1.0], device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if float(ok.item()) == 1.0:
+        return sync
+    if sync is not None:
+        sync.close()
+    if rank == 0:
+        print("geglove: the library's RCCL communicator did not come up (%s); exchanging through torch.distributed instead" % (err,), flush=True)
+    return ContextSync(optimizer, world, rank, wire=wire, accum_every=lazy_every, transport="torch", device=device, group=group)
