@@ -12,6 +12,7 @@
 #pragma once
 
 #include <algorithm>
+#include <charconv>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -54,19 +55,26 @@ inline void check(ge_status s) {
 // ------------------------------------------------------------------------------------------------
 // Java number -> string conversions used by the writer header and the file name
 // ------------------------------------------------------------------------------------------------
-inline std::string shortest_digits(double a, int max_prec, int &exp10) {   // digits d1d2..., value = 0.d1d2.. * 10^(exp10+1)
+// Shortest decimal digits that read back as `a` (as a float when max_prec == 8), correctly rounded: what Double.toString /
+// Float.toString print.  std::to_chars gives exactly that (shortest round-trip, closest among the shortest) without the
+// print-and-parse loop; n = number of digits written to dig[], value = d1.d2d3... * 10^exp10.
+inline int shortest_digits_fast(double a, bool as_float, char *dig, int &exp10) {
     char buf[64];
-    int prec = 0;
-    for (; prec <= max_prec; ++prec) {
-        std::snprintf(buf, sizeof buf, "%.*e", prec, a);
-        if (max_prec == 8 ? (float)std::strtod(buf, nullptr) == (float)a : std::strtod(buf, nullptr) == a) break;
-    }
-    const char *e = std::strchr(buf, 'e');
-    exp10 = std::atoi(e + 1);
-    std::string d;
-    for (const char *q = buf; q < e; ++q) if (*q >= '0' && *q <= '9') d.push_back(*q);
-    while (d.size() > 1 && d.back() == '0') d.pop_back();
-    return d;
+    const std::to_chars_result r = as_float ? std::to_chars(buf, buf + sizeof buf, (float)a, std::chars_format::scientific)
+                                            : std::to_chars(buf, buf + sizeof buf, a, std::chars_format::scientific);
+    int n = 0;
+    const char *q = buf;
+    for (; q < r.ptr && *q != 'e'; ++q) if (*q >= '0' && *q <= '9') dig[n++] = *q;
+    int ex = 0; bool neg = false;
+    for (++q; q < r.ptr; ++q) { if (*q == '-') neg = true; else if (*q >= '0' && *q <= '9') ex = ex * 10 + (*q - '0'); }
+    exp10 = neg ? -ex : ex;
+    while (n > 1 && dig[n - 1] == '0') --n;
+    return n;
+}
+inline std::string shortest_digits(double a, int max_prec, int &exp10) {   // digits d1d2..., value = 0.d1d2.. * 10^(exp10+1)
+    char dig[32];
+    const int n = shortest_digits_fast(a, max_prec == 8, dig, exp10);
+    return std::string(dig, (size_t)n);
 }
 // Double.toString / Float.toString: decimal for 1e-3 <= |x| < 1e7, otherwise d.dddE[-]n
 inline std::string java_number(double v, bool is_float) {
@@ -90,26 +98,34 @@ inline std::string java_number(double v, bool is_float) {
     }
     return out;
 }
-// String.format("%11.6E", v): HALF_UP on the shortest repr digits (EmbeddingTextWriter.java:134)
-inline std::string java_format_11_6E(double v) {
-    if (v != v) return "        NaN";
-    char body[48];
-    if (std::isinf(v)) { std::snprintf(body, sizeof body, "%11s", v > 0 ? "Infinity" : "-Infinity"); return body; }
-    int ex = 0;
-    std::string d = v == 0 ? std::string("0") : shortest_digits(std::fabs(v), 17, ex);
+// String.format("%11.6E", v): HALF_UP on the shortest repr digits (EmbeddingTextWriter.java:134).  Writes the field (at least
+// 11 characters, right-aligned) to out and returns its length; out holds >= 32 characters.
+inline int java_format_11_6E_to(double v, char *out) {
+    if (v != v) { std::memcpy(out, "        NaN", 11); return 11; }
+    if (std::isinf(v)) { const char *t = v > 0 ? "   Infinity" : "  -Infinity"; std::memcpy(out, t, 11); return 11; }
+    int ex = 0; char d[32]; int n = 1;
+    if (v == 0) d[0] = '0'; else n = shortest_digits_fast(std::fabs(v), false, d, ex);
     int dig[7];
-    for (int k = 0; k < 7; ++k) dig[k] = k < (int)d.size() ? d[(size_t)k] - '0' : 0;
-    if (d.size() > 7 && d[7] >= '5') {
+    for (int k = 0; k < 7; ++k) dig[k] = k < n ? d[k] - '0' : 0;
+    if (n > 7 && d[7] >= '5') {
         int k = 6;
         while (k >= 0) { if (++dig[k] < 10) break; dig[k] = 0; --k; }
         if (k < 0) { dig[0] = 1; for (int q = 1; q < 7; ++q) dig[q] = 0; ++ex; }
     }
-    std::snprintf(body, sizeof body, "%s%d.%d%d%d%d%d%dE%c%02d", std::signbit(v) ? "-" : "", dig[0], dig[1], dig[2], dig[3],
-                  dig[4], dig[5], dig[6], ex < 0 ? '-' : '+', ex < 0 ? -ex : ex);
-    char out[64];
-    std::snprintf(out, sizeof out, "%11s", body);
-    return out;
+    char body[24]; int m = 0;
+    if (std::signbit(v)) body[m++] = '-';
+    body[m++] = (char)('0' + dig[0]); body[m++] = '.';
+    for (int k = 1; k < 7; ++k) body[m++] = (char)('0' + dig[k]);
+    body[m++] = 'E'; body[m++] = ex < 0 ? '-' : '+';
+    const int ax = ex < 0 ? -ex : ex;
+    if (ax >= 100) body[m++] = (char)('0' + ax / 100);
+    body[m++] = (char)('0' + (ax / 10) % 10); body[m++] = (char)('0' + ax % 10);
+    int len = 0;
+    for (int k = m; k < 11; ++k) out[len++] = ' ';
+    std::memcpy(out + len, body, (size_t)m);
+    return len + m;
 }
+inline std::string java_format_11_6E(double v) { char out[32]; const int n = java_format_11_6E_to(v, out); return std::string(out, (size_t)n); }
 
 // ------------------------------------------------------------------------------------------------
 // YAML subset: block maps, block lists ("- "), flow lists [a, b], scalars, comments.  That is all
@@ -1086,23 +1102,51 @@ public:
         const int V = m.vocabSize(), D = config_.dim;
         static const char *names[3] = {"URI", "BLANK", "LITERAL"};
         long long written = 0;
-        std::string row;
+        // which vertices are written (type switch, then the prefix filter of that type: EmbeddingTextWriter.java:100-131), in order
+        std::vector<int> keep;
         for (int i = 0; i < V; ++i) {
             const int8_t type = m.getType(i);
             if (!write_[type]) continue;
-            const std::string key = m.getKey(i);
             const std::vector<std::string> &pre = type == URI ? config_.output.uri : type == BLANK ? config_.output.blank : config_.output.literal;
             if (!pre.empty()) {
+                const std::string key = m.getKey(i);
                 bool any = false;
                 for (auto &p : pre) if (key.compare(0, p.size(), p) == 0) { any = true; break; }
                 if (!any) continue;
             }
-            row.clear();
-            for (int d = 0; d < D; ++d) { if (d) row.push_back('\t'); row += java_format_11_6E(optimum.result[(size_t)d + (size_t)i * D]); }
-            vect << row << "\n";
+            keep.push_back(i);
+        }
+        // the text of the vectors file is 13 bytes per value (60 M values for 300 k vertices at dim 200): blocks of rows are
+        // formatted by all host threads, written in order
+        const int T = std::max(1, std::min(config_.getThreads() > 1 ? config_.getThreads() : (int)std::thread::hardware_concurrency(), 32));
+        const size_t block = 2048;
+        std::vector<std::string> part((size_t)T);
+        for (size_t base = 0; base < keep.size(); base += block * (size_t)T) {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) {
+                const size_t lo = std::min(keep.size(), base + block * (size_t)t), hi = std::min(keep.size(), lo + block);
+                part[(size_t)t].clear();
+                if (lo >= hi) continue;
+                th.emplace_back([&, t, lo, hi] {
+                    std::string &buf = part[(size_t)t];
+                    buf.resize((hi - lo) * ((size_t)D * 33 + 1));        // one field is at most 26 characters + a tab
+                    size_t w = 0;
+                    for (size_t k = lo; k < hi; ++k) {
+                        const size_t i = (size_t)keep[k];
+                        for (int d = 0; d < D; ++d) { if (d) buf[w++] = '\t'; w += (size_t)java_format_11_6E_to(optimum.result[(size_t)d + i * (size_t)D], &buf[w]); }
+                        buf[w++] = '\n';
+                    }
+                    buf.resize(w);
+                });
+            }
+            for (auto &x : th) x.join();
+            for (int t = 0; t < T; ++t) vect.write(part[(size_t)t].data(), (std::streamsize)part[(size_t)t].size());
+        }
+        for (int i : keep) {
+            const std::string key = m.getKey(i);
             std::string clean;
             for (char ch : key) if (ch != '\n' && ch != '\r' && ch != '\t') clean.push_back(ch);
-            dict << clean << "\t" << names[type] << "\n";
+            dict << clean << "\t" << names[m.getType(i)] << "\n";
             ++written;
         }
         return written;

@@ -98,8 +98,13 @@ def test_java_number_formats(host):
     assert host.geh_java_double(1e-4) == b"1.0E-4" and host.geh_java_double(12345678.0) == b"1.2345678E7"
     assert host.geh_java_double(100.0) == b"100.0" and host.geh_java_float(0.1) == b"0.1" and host.geh_java_float(1.0) == b"1.0"
     rng = np.random.default_rng(0)
-    for v in np.concatenate([rng.standard_normal(200) * 10.0 ** rng.integers(-8, 8, 200), [0.12345675, 9.9999999e-5, 0.0, -2.5]]):
-        assert host.geh_format_11_6E(float(v)).decode() == O.format_11_6E(float(v))     # two implementations, one spec
+    wide = rng.standard_normal(3000) * 10.0 ** rng.integers(-8, 8, 3000)
+    floats = (rng.standard_normal(3000) * 10.0 ** rng.integers(-6, 3, 3000)).astype(np.float32).astype(np.float64)   # what the writer gets: widened floats
+    edge = [0.12345675, 9.9999999e-5, 0.0, -0.0, -2.5, 9.9999995, 9.9999994e7, 1e100, -3.3e-120, 5e-324, 1.7976931348623157e308, 1e-5, 123456.75]
+    for v in np.concatenate([wide, floats, edge]):
+        assert host.geh_format_11_6E(float(v)).decode() == O.format_11_6E(float(v)), v   # two implementations (std::to_chars / print-and-parse), one spec
+    assert host.geh_format_11_6E(0.12345675) == b"1.234568E-01"       # HALF_UP on the shortest digits 12345675 (a binary double slightly below ...75)
+    assert host.geh_format_11_6E(1e100) == b"1.000000E+100" and host.geh_format_11_6E(-2.5) == b"-2.500000E+00" and host.geh_format_11_6E(0.0) == b"0.000000E+00"
 
 
 def test_yaml_subset_bean_and_file_name(host):
