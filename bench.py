@@ -198,7 +198,7 @@ def main():
     if rank == 0:
         import ctypes
         g = ctypes.c_double(0.0)
-        if capi.lib().ge_copy_bandwidth(local_rank, 2 << 30, 5, ctypes.byref(g)) == 0:
+        if capi.lib().ge_copy_bandwidth(local_rank, 1 << 30, 5, ctypes.byref(g)) == 0:
             box_copy = g.value
 
     total_updates = n_local * args.steps

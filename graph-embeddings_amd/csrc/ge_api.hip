@@ -1,5 +1,6 @@
 // ge_api.hip -- error buffer, device selection, version: the parts of the C ABI that no kernel owns.
 #include "ge_common.h"
+#include <algorithm>
 #include <cstring>
 
 namespace ge {
@@ -29,13 +30,16 @@ ge_status select_device(int device) {
 }  // namespace ge
 
 namespace {
+template <int U>
 __global__ __launch_bounds__(256) void k_copy16(float4 *__restrict__ dst, const float4 *__restrict__ src, int64_t n4) {
-    // four 16-byte loads in flight per lane before the first store
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        float4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[i + u * stride] = r[u];
     }
     for (; i < n4; i += stride) dst[i] = src[i];
 }
@@ -44,7 +48,9 @@ __global__ __launch_bounds__(256) void k_copy16(float4 *__restrict__ dst, const 
 extern "C" {
 
 // What this device's memory system gives a plain 16-byte-per-lane copy (bytes read + bytes written per second): the practical
-// ceiling a streaming kernel is measured against (MI355X_MICROARCH.md: 6.29 TB/s), taken on the box the bench runs on.
+// ceiling a streaming kernel is measured against, taken on the box the bench runs on.  The best of a few launch shapes
+// (tools/micro/copybench.hip: 2 or 4 workgroups per CU, one or two loads in flight per lane; 4.4 - 5.8 TB/s on the boxes of this
+// pool, against the 6.29 TB/s MI355X_MICROARCH.md quotes).
 ge_status ge_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, double *gbps) {
     if (!gbps || bytes < (1 << 20) || reps < 1) return ge::fail(GE_ERR_ARG, "ge_copy_bandwidth: need >= 1 MiB, >= 1 repetition and an output");
     ge_status st = ge::select_device(device);
@@ -57,20 +63,27 @@ ge_status ge_copy_bandwidth(int32_t device, int64_t bytes, int32_t reps, double 
     if (e == hipSuccess) e = hipMemset(a, 1, (size_t)n4 * 16);
     if (e == hipSuccess) e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    float ms = 0;
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_copy16, dim3(256 * 8), dim3(256), 0, 0, b, a, n4);                       // warm-up
+    double best = 0;
+    for (int shape = 0; shape < 4 && e == hipSuccess; ++shape) {
+        const int blocks = (shape & 1) ? 1024 : 512;
+        auto launch = [&]() {
+            if (shape < 2) hipLaunchKernelGGL(k_copy16<1>, dim3(blocks), dim3(256), 0, 0, b, a, n4);
+            else hipLaunchKernelGGL(k_copy16<2>, dim3(blocks), dim3(256), 0, 0, b, a, n4);
+        };
+        launch();                                                       // warm-up
         e = hipEventRecord(e0, 0);
-        for (int r = 0; r < reps && e == hipSuccess; ++r) hipLaunchKernelGGL(k_copy16, dim3(256 * 8), dim3(256), 0, 0, b, a, n4);
+        for (int r = 0; r < reps && e == hipSuccess; ++r) launch();
         if (e == hipSuccess) e = hipEventRecord(e1, 0);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0;
         if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && ms > 0) best = std::max(best, 2.0 * (double)n4 * 16.0 * reps / ((double)ms * 1e-3) / 1e9);
     }
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     (void)hipFree(a); if (b) (void)hipFree(b);
     if (e != hipSuccess) return ge::fail(GE_ERR_HIP, "ge_copy_bandwidth: %s", hipGetErrorString(e));
-    *gbps = 2.0 * (double)n4 * 16.0 * reps / ((double)ms * 1e-3) / 1e9;
+    *gbps = best;
     return GE_OK;
 }
 
