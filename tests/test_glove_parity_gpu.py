@@ -129,7 +129,8 @@ def _worker_order(perm, J, hot, n_workers, chunk=128):
 
 
 @pytest.mark.parametrize("hot", ["none", "all", "auto"])
-@pytest.mark.parametrize("method,D", [("glove", 200), ("pglove", 50), ("glove", 300), ("pglove", 6)])
+@pytest.mark.parametrize("method,D", [("glove", 200), ("pglove", 50), ("glove", 300), ("pglove", 6),
+                                      ("glove", 1024), ("glove", 255), ("pglove", 510), ("glove", 256), ("pglove", 2)])   # every lane shape: 4 x 4 chunks, odd, even, full chunks, two floats
 def test_hogwild_blocked_order_single_worker_replays_sequentially(gpu, method, D, hot, monkeypatch):
     """DEVICE shuffle = blocked order (hub columns column-major, the rest row-major, chunks of 128 permuted per
     epoch).  With one worker the kernel is a sequential program; the library reports the order it walks
