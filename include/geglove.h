@@ -403,7 +403,8 @@ ge_status ge_rccl_unique_id(void *id128);
  * single-GPU machine can verify of the RCCL path. */
 ge_status ge_rccl_selftest(int32_t device);
 int32_t ge_sync_cfg_size(void);
-/* Collective: every rank calls it (RCCL: ncclCommInitRank inside).  The base of every table is its value NOW. */
+/* Collective: every rank calls it (RCCL: ncclCommInitRank inside).  The base of every table is its value NOW.  A ge_sync
+ * works on its handle's device tables: destroy it before the ge_glove it was created for. */
 ge_status ge_sync_create(ge_glove *h, const ge_sync_cfg *cfg, ge_sync **out);
 /* begin = take: the deltas since the last take go on the wire (everything != 0: accumulators too), asynchronously on RCCL's
  * own stream.  finish = land: waits for them and adds what the OTHER ranks sent.  turn = finish, then begin: the all-reduce of
