@@ -73,7 +73,8 @@ enum { GE_SHUFFLE_JAVA = 0, GE_SHUFFLE_DEVICE = 1, GE_SHUFFLE_NONE = 2 };
  * context side with float atomic adds (no update is lost; gradients may be a few microseconds
  * stale, as under Hogwild) and read it with agent-coherent loads.
  * AUTO: column j is hot when  count(j) * groups_in_flight >= 0.25 * N  (library default).
- * NONE: plain stores everywhere (the literal Java race).  ALL: every column (tests). */
+ * NONE: no column is treated as a hub: context rows are always read, updated and stored plainly (the literal Java race on that
+ *   side; focus rows are still never overwritten, see GE_LAYOUT_*).  ALL: every column (tests). */
 enum { GE_HOT_AUTO = 0, GE_HOT_NONE = 1, GE_HOT_ALL = 2 };
 
 /* Storage type of the embedding rows (focus, context).  BF16 is BASELINE config C5: bf16 rows, fp32 AdaGrad
