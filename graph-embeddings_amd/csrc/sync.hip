@@ -157,22 +157,22 @@ struct Rccl {
 };
 Rccl &rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
-    // a copy that is already in the process (PyTorch-ROCm bundles one) wins: one RCCL per process
-    static const char *names[] = {"librccl.so.1", "librccl.so"};
-    for (const char *n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-    static const char *paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-    for (const char *n : paths) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (!r.lib) return r;
-    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
-    r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
-    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
-    r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
-    r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
-    r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.Broadcast && r.GetErrorString;
+    static std::once_flag once;                 // rank threads of one process may arrive together
+    std::call_once(once, [] {
+        // a copy that is already in the process (PyTorch-ROCm bundles one) wins: one RCCL per process
+        static const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *n : names) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        static const char *paths[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        for (const char *n : paths) if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!r.lib) return;
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+        r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.Broadcast && r.GetErrorString;
+    });
     return r;
 }
 #define GE_NCCL(expr)                                                                                              \
