@@ -373,6 +373,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// four bf16 values (8 bytes) widened to fp32
+__device__ __forceinline__ float4 widen_bf16x4(float2 raw) {
+    const uint32_t lo = __builtin_bit_cast(uint32_t, raw.x), hi = __builtin_bit_cast(uint32_t, raw.y);
+    float4 r;
+    r.x = __builtin_bit_cast(float, lo << 16); r.y = __builtin_bit_cast(float, lo & 0xFFFF0000u);
+    r.z = __builtin_bit_cast(float, hi << 16); r.w = __builtin_bit_cast(float, hi & 0xFFFF0000u);
+    return r;
+}
+#define GE_LDS(ptr) ((__attribute__((address_space(3))) void *)(ptr))
+// s_waitcnt immediate (gfx9 layout) that waits until at most n vector-memory instructions are outstanding and for nothing else
+constexpr int wait_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
+
 constexpr int RUN_CHUNK = 128;            // nonzeros per worker chunk (2 per lane)
 constexpr int KEY_PAD = 0x7FFFFFFF;       // sorts last; marks the unused tail of the last chunk
 
@@ -383,7 +395,7 @@ constexpr int KEY_PAD = 0x7FFFFFFF;       // sorts last; marks the unused tail o
 //   would always round away).  Hub context rows keep an fp32 master copy (hub32) that their runs read and
 //   publish into with the same atomics as in the fp32 build; they never touch the bf16 table during training.
 template <int VW, int NCH, int OPT, bool EMB16, bool FAT>
-__global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_workers) {
+__global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD) ? 5 : 1) void k_adagrad_runs(GloveParams p, int32_t n_workers) {
     static_assert(!(EMB16 && FAT), "bf16 rows keep their biases in separate tables");
     using VT = typename Vec<VW>::T;
     static_assert(!EMB16 || VW == 4, "bf16 embeddings need dim % 4 == 0");
@@ -400,14 +412,8 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
         else return make_rsrc(base + id * p.DS, (uint32_t)p.RW * 4u);
     };
     auto emb_load = [&](__amdgpu_buffer_rsrc_t rs, int q) -> VT {
-        if constexpr (EMB16) {
-            const float2 raw = buf_load<2, AUX_SC1>(rs, ((threadIdx.x & 63) + q * 64) * 8);
-            const uint32_t lo = __builtin_bit_cast(uint32_t, raw.x), hi = __builtin_bit_cast(uint32_t, raw.y);
-            VT r;
-            r.x = __builtin_bit_cast(float, lo << 16); r.y = __builtin_bit_cast(float, lo & 0xFFFF0000u);
-            r.z = __builtin_bit_cast(float, hi << 16); r.w = __builtin_bit_cast(float, hi & 0xFFFF0000u);
-            return r;
-        } else return buf_load<VW, AUX_SC1>(rs, ((threadIdx.x & 63) + q * 64) * VW * 4);
+        if constexpr (EMB16) return widen_bf16x4(buf_load<2, AUX_SC1>(rs, ((threadIdx.x & 63) + q * 64) * 8));
+        else return buf_load<VW, AUX_SC1>(rs, ((threadIdx.x & 63) + q * 64) * VW * 4);
     };
     auto emb_store = [&](VT v, __amdgpu_buffer_rsrc_t rs, int q) {
         if constexpr (EMB16) {
@@ -440,6 +446,19 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
     if (wave >= n_workers) return;          // workers pull chunks of the epoch order from one queue
     const int64_t n_chunks = p.n_chunks;
     __shared__ float s_tr[4][2][NCH * 64 * VW];       // per-wave strip for the atomic flush (no block barrier)
+    // The streamed rows of the NEXT nonzero land in LDS, not in registers (buffer_load ... lds, 16 bytes per lane): nothing
+    // in the register file depends on the load, so it stays in flight across the current nonzero's arithmetic and stores
+    // and is waited for only where the next step reads it (with loads into registers the compiler put the copies that merge
+    // the two steps' values -- and with them the wait -- right behind the load, and every nonzero paid the full latency).
+    // Two images per wave, one per array, so that the wait for one never covers the load into the other.
+    constexpr bool DMA = VW == 4;
+    constexpr int IMG = 256;                                                         // floats per 1 KB image: 64 lanes x 16 bytes
+    constexpr int IMG_R = EMB16 ? ((NCH + 1) / 2) * IMG : NCH * IMG;               // a bf16 row takes half the bytes
+    constexpr int IMG_G = IMG_R, IMG_H = IMG_G + NCH * IMG;                          // offsets of the accumulator / second-moment images
+    constexpr int IMG_B = IMG_H + (MOM ? NCH * IMG : 0);                             // three 256-byte slots for the bias scalars (not FAT)
+    constexpr int SET_FLOATS = IMG_B + (FAT ? 0 : 3 * 64);
+    __shared__ float s_setA[DMA ? 4 * SET_FLOATS : 1], s_setB[DMA ? 4 * SET_FLOATS : 1];
+    float *const setA = s_setA + (DMA ? (threadIdx.x >> 6) * SET_FLOATS : 0), *const setB = s_setB + (DMA ? (threadIdx.x >> 6) * SET_FLOATS : 0);
     double cost_acc = 0.0;
     bool inr[NCH];                          // lane holds real elements of a row (D % VW == 0)
 #pragma unroll
@@ -530,7 +549,17 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
         bool cur_a32 = !EMB16, n_a32 = !EMB16;       // EMB16: resident parameter row lives in hub32 (fp32) for hub chunks
         VT a[NCH], ga[NCH], ha[NCH], a0[NCH], ga0[NCH];     // ha = second moment (MOM); ga0 = gradSq as read (AdaGrad)
         float ab = 0.0f, gab = 0.0f, hab = 0.0f;
-        __amdgpu_buffer_rsrc_t rs_a = make_rsrc(A_rows, 0), rs_ga = rs_a, rs_ha = rs_a;
+        // the resident rows' resources are rebuilt from the row id where they are used (once per run): kept in SGPRs across the
+        // walk they cost 24 registers, and what does not fit there spills into vector registers
+        int32_t cur_slot = 0, n_slot = 0;            // EMB16 hub chunk: the row's slot in hub32; else the row id
+        auto res_rows = [&](int32_t id, int32_t slot, bool a32) -> __amdgpu_buffer_rsrc_t {
+            if constexpr (EMB16) {
+                if (a32) return make_rsrc(p.hub32 + (int64_t)slot * D, row_bytes);
+                return make_rsrc(reinterpret_cast<uint16_t *>(A_rows) + (int64_t)id * p.ES, (uint32_t)p.D * 2u);
+            } else return make_rsrc(A_rows + (int64_t)id * DS, row_bytes);
+        };
+        auto res_gs = [&](int32_t id) { return make_rsrc(A_gs + (int64_t)id * DS, row_bytes); };
+        auto res_m2 = [&](int32_t id) { return make_rsrc(A_m2 + (int64_t)id * DS, MOM ? row_bytes : 0u); };
 
         auto close_run = [&]() {
             // How a run's result leaves the registers:
@@ -544,6 +573,7 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             // not ADD their moves (measured: the cost climbs again after a few epochs); they are merged last-writer-wins,
             // parameters and moments alike, which is exactly the Java race.  The run is still cut and re-read every
             // flush_lim nonzeros, so workers on one hub stay within that many updates of each other.
+            const __amdgpu_buffer_rsrc_t rs_a = res_rows(cur_id, cur_slot, cur_a32), rs_ga = res_gs(cur_id), rs_ha = res_m2(cur_id);
             const bool store_all = !cur_hot || (MOM && res_is_ctx);
             const bool rmw_row = !store_all && !res_is_ctx && (MOM || (EMB16 && !cur_a32));
             if (store_all || (rmw_row && MOM)) {
@@ -620,9 +650,10 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
 
         // decoded next nonzero + its prefetched rows
         int32_t n_oth = 0, n_key = KEY_PAD; float n_w = 0.0f; double n_l = 0.0;
-        VT nb[NCH], ngb[NCH], nhb[NCH]; float n_bb = 0.0f, n_gbb = 0.0f, n_hbb = 0.0f;
+        // Register sets for the streamed rows where the rows cannot go through LDS (VW < 4: no 16-byte lanes).
+        struct Streamed { VT r[NCH], g[NCH], h[NCH]; float bb, gbb, hbb; };
+        Streamed sA{}, sB{};
         VT aN[NCH], gaN[NCH], haN[NCH]; float abN = 0.0f, gabN = 0.0f, habN = 0.0f;
-        __amdgpu_buffer_rsrc_t rsN_a = rs_a, rsN_ga = rs_a, rsN_ha = rs_a;
         auto decode = [&](int pos) {
             const int q = pos >> 6, ln = pos & 63;
             n_key = __builtin_amdgcn_readlane(q ? key[1] : key[0], ln);
@@ -635,31 +666,71 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(lb >> 32), sln);
             n_l = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
         };
-        auto request_streamed = [&]() {
-            const __amdgpu_buffer_rsrc_t rb = emb_rsrc(B_rows, n_oth);
-            const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)n_oth * DS, row_bytes);
-            const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)n_oth * DS, MOM ? row_bytes : 0u);
+        // Requests the streamed rows of nonzero n_oth into set SET (0: A, 1: B).  `live` false: the same instructions against
+        // zero-sized resources -- nothing is read, zeros arrive.  Issued on EVERY step, so that the number of memory
+        // instructions between a request and its use is the same on every path and the wait can be counted.
+        auto request_streamed = [&](auto SET, const bool live) {
+            const uint32_t rbytes = live ? row_bytes : 0u, ebytes = live ? (uint32_t)p.D * 2u : 0u, four = live ? 4u : 0u;
+            __amdgpu_buffer_rsrc_t rb;
+            if constexpr (EMB16) rb = make_rsrc(reinterpret_cast<uint16_t *>(B_rows) + (int64_t)n_oth * p.ES, ebytes);
+            else rb = make_rsrc(B_rows + (int64_t)n_oth * DS, rbytes);
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)n_oth * DS, rbytes);
+            const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)n_oth * DS, MOM ? rbytes : 0u);
+            if constexpr (DMA) {
+                float *const img = decltype(SET)::value ? setB : setA;
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                nb[q]  = emb_load(rb, q);
-                ngb[q] = buf_load<VW, AUX_SC1>(rg, (lane + q * 64) * VW * 4);
-                if constexpr (MOM) nhb[q] = buf_load<VW, AUX_SC1>(rh, (lane + q * 64) * VW * 4);
+                for (int j = 0; j < IMG_R / IMG; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, GE_LDS(img + j * IMG), 16, (lane + j * 64) * 16, 0, 0, AUX_SC1);
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, GE_LDS(img + IMG_G + q * IMG), 16, (lane + q * 64) * 16, 0, 0, AUX_SC1);
+                    if constexpr (MOM) __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, GE_LDS(img + IMG_H + q * IMG), 16, (lane + q * 64) * 16, 0, 0, AUX_SC1);
+                }
+                if constexpr (!FAT) {                  // lane 0 is the one lane inside these 4-byte resources
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(B_bias + n_oth, four), GE_LDS(img + IMG_B), 4, lane * 4, 0, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(B_gsb + n_oth, four), GE_LDS(img + IMG_B + 64), 4, lane * 4, 0, 0, AUX_SC1);
+                    if constexpr (MOM) __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(B_m2b + n_oth, four), GE_LDS(img + IMG_B + 128), 4, lane * 4, 0, 0, AUX_SC1);
+                }
+                asm volatile("" ::: "memory");          // issued here, not where the scheduler would like them
+            } else {
+                Streamed &s = decltype(SET)::value ? sB : sA;
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    s.r[q] = emb_load(rb, q);
+                    s.g[q] = buf_load<VW, AUX_SC1>(rg, (lane + q * 64) * VW * 4);
+                    if constexpr (MOM) s.h[q] = buf_load<VW, AUX_SC1>(rh, (lane + q * 64) * VW * 4);
+                }
+                if constexpr (!FAT) {
+                    s.bb  = buf_load_f32(make_rsrc(B_bias + n_oth, four), 0, true);
+                    s.gbb = buf_load_f32(make_rsrc(B_gsb + n_oth, four), 0, true);
+                    if constexpr (MOM) s.hbb = buf_load_f32(make_rsrc(B_m2b + n_oth, four), 0, true);
+                }
             }
-            if constexpr (!FAT) {
-                n_bb  = buf_load_f32(make_rsrc(B_bias + n_oth, 4), 0, true);
-                n_gbb = buf_load_f32(make_rsrc(B_gsb + n_oth, 4), 0, true);
-                if constexpr (MOM) n_hbb = buf_load_f32(make_rsrc(B_m2b + n_oth, 4), 0, true);
+        };
+        // waits until set SET has arrived (reads it), so that nothing of it is pending on the path that calls this
+        auto settle = [&](auto SET) {
+            if constexpr (DMA) { __builtin_amdgcn_s_waitcnt(wait_vmcnt(0)); asm volatile("" ::: "memory"); }
+            else {
+                Streamed &s = decltype(SET)::value ? sB : sA;
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+#pragma unroll
+                    for (int t = 0; t < VW; ++t) {
+                        asm volatile("" : "+v"(comp<VW>(s.r[q], t)), "+v"(comp<VW>(s.g[q], t)));
+                        if constexpr (MOM) asm volatile("" : "+v"(comp<VW>(s.h[q], t)));
+                    }
+                }
+                if constexpr (!FAT) asm volatile("" : "+v"(s.bb), "+v"(s.gbb), "+v"(s.hbb));
             }
         };
         auto request_resident = [&]() {
             const int32_t id = n_key < 0 ? ~n_key : n_key;
+            n_slot = id;
             if constexpr (EMB16) {
                 n_a32 = res_is_ctx && p.hot_enabled != 0;                  // hub chunk: fp32 master row
-                if (n_a32) rsN_a = make_rsrc(p.hub32 + (int64_t)p.hub_index[id] * D, row_bytes);
-                else rsN_a = emb_rsrc(A_rows, id);
-            } else rsN_a = make_rsrc(A_rows + (int64_t)id * DS, row_bytes);
-            rsN_ga = make_rsrc(A_gs + (int64_t)id * DS, row_bytes);
-            rsN_ha = make_rsrc(A_m2 + (int64_t)id * DS, MOM ? row_bytes : 0u);
+                if (n_a32) n_slot = rfl(p.hub_index[id]);
+            }
+            const __amdgpu_buffer_rsrc_t rsN_a = res_rows(id, n_slot, n_a32), rsN_ga = res_gs(id), rsN_ha = res_m2(id);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
                 if (EMB16 && !n_a32) aN[q] = emb_load(rsN_a, q);
@@ -676,23 +747,36 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
 
         bool open_new = true;
         int run_len = 0;
-        if (n_valid > 0) { decode(0); request_streamed(); request_resident(); }
-        for (int pos = 0; pos < n_valid; ++pos) {
+        // the staged nonzeros have arrived before the walk starts: inside it only row traffic is pending
+        asm volatile("" : "+v"(oth[0]), "+v"(oth[1]), "+v"(ww[0]), "+v"(ww[1]), "+v"(ll[0]), "+v"(ll[1]));
+        bool again = false;
+        // One nonzero.  CUR (0 / 1) names the set that holds its streamed rows; the other set is requested for the next one first
+        // thing, before this step waits for anything.
+        auto step = [&](const int pos, auto CUR) {
+            constexpr std::integral_constant<int, 1 - decltype(CUR)::value> NXT{};
             const int32_t b_id = n_oth, skey = n_key;
             const float w = n_w; const double l = n_l;
-            VT b[NCH], gb[NCH], hb[NCH];
-#pragma unroll
-            for (int q = 0; q < NCH; ++q) { b[q] = nb[q]; gb[q] = ngb[q]; if constexpr (MOM) hb[q] = nhb[q]; }
-            float bb = n_bb, gbb = n_gbb, hbb = n_hbb;
-            if constexpr (FAT) {
-#pragma unroll
-                for (int q = 0; q < NCH; ++q)
-                    if (q == bl_q) {
-                        bb  = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(b[q], 0)), bl_lane));
-                        gbb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(gb[q], 0)), bl_lane));
-                        if constexpr (MOM) hbb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(hb[q], 0)), bl_lane));
-                    }
+            // the previous nonzero had the same streamed row: what was requested before its stores is stale.  Re-read behind
+            // them (same wave, same address: in order) and wait right here, so that on the common path the set is known to be
+            // older than those stores and the wait for it leaves them in flight.
+            if (again) { request_streamed(CUR, true); settle(CUR); again = false; }
+            if (open_new) {                       // the scalars of a new run; its rows follow below
+                cur_id = skey < 0 ? ~skey : skey;
+                // shared = other workers may hold this row too: hub columns (context side), pieces of a long focus row
+                cur_hot = p.blocked ? (res_is_ctx ? p.hot_enabled != 0 : cur_id == c_meta) : skey < 0;
+                cur_slot = n_slot;
+                cur_a32 = n_a32;
+                run_len = 0;
             }
+            const bool last = pos + 1 >= n_valid;
+            bool next_new = false;
+            if (!last) {
+                decode(pos + 1);
+                again = n_oth == b_id;
+                // a long hub run is cut every flush_lim nonzeros: publish the delta, re-read what the other workers published
+                next_new = n_key != skey || (cur_hot && run_len + 1 >= flush_lim);
+            }
+            request_streamed(NXT, !last);
             if (open_new) {
 #pragma unroll
                 for (int q = 0; q < NCH; ++q) {
@@ -709,21 +793,48 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
                             if constexpr (MOM) hab = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(ha[q], 0)), bl_lane));
                         }
                 }
-                cur_id = skey < 0 ? ~skey : skey;
-                // shared = other workers may hold this row too: hub columns (context side), pieces of a long focus row
-                cur_hot = p.blocked ? (res_is_ctx ? p.hot_enabled != 0 : cur_id == c_meta) : skey < 0;
-                rs_a = rsN_a; rs_ga = rsN_ga; rs_ha = rsN_ha;
-                cur_a32 = n_a32;
-                run_len = 0;
             }
-            const bool last = pos + 1 >= n_valid;
-            bool deferred = false, next_new = false;
-            if (!last) {
-                decode(pos + 1);
-                if (n_oth != b_id) request_streamed(); else deferred = true;   // same streamed row twice in a row: re-read after the store
-                // a long hub run is cut every p.flush_every nonzeros: publish the delta, re-read what the other workers published
-                next_new = n_key != skey || (cur_hot && run_len + 1 >= flush_lim);
-                if (next_new) request_resident();
+            if (next_new) request_resident();     // after the copies above: it refills aN
+            // this nonzero's streamed rows
+            VT bl[NCH], gbl[NCH], hbl[NCH];
+            float bb = 0.0f, gbb = 0.0f, hbb = 0.0f;
+            if constexpr (DMA) {
+                // The wait is counted by hand (the compiler's own bookkeeping of loads into LDS loses them across the loop's
+                // back edge).  Memory instructions complete in order, and behind this set's request at least N_AFTER more
+                // have been issued on every path: the previous step's stores, one per table and register chunk (never
+                // skipped: lane 0 of every chunk holds row elements), or before the first step the resident rows' loads, one per
+                // table and chunk as well; then the request for the other set a few lines up.
+                constexpr int N_TAB = NCH * (2 + (MOM ? 1 : 0)) + (FAT ? 0 : 2 + (MOM ? 1 : 0));
+                constexpr int N_DMA = IMG_R / IMG + NCH * (1 + (MOM ? 1 : 0)) + (FAT ? 0 : 2 + (MOM ? 1 : 0));
+                constexpr int N_AFTER = N_TAB + N_DMA;
+                static_assert(N_AFTER < 64, "vmcnt is a 6-bit counter");
+                __builtin_amdgcn_s_waitcnt(wait_vmcnt(N_AFTER));       // the builtin, not asm text: the compiler's bookkeeping sees it
+                asm volatile("" ::: "memory");
+                const float *const img = decltype(CUR)::value ? setB : setA;
+#pragma unroll
+                for (int q = 0; q < NCH; ++q) {
+                    if constexpr (EMB16) bl[q] = widen_bf16x4(*reinterpret_cast<const float2 *>(img + (lane + q * 64) * 2));
+                    else bl[q] = *reinterpret_cast<const VT *>(img + (lane + q * 64) * 4);
+                    gbl[q] = *reinterpret_cast<const VT *>(img + IMG_G + (lane + q * 64) * 4);
+                    if constexpr (MOM) hbl[q] = *reinterpret_cast<const VT *>(img + IMG_H + (lane + q * 64) * 4);
+                }
+                if constexpr (!FAT) { bb = img[IMG_B]; gbb = img[IMG_B + 64]; if constexpr (MOM) hbb = img[IMG_B + 128]; }
+            } else {
+                const Streamed &cs = decltype(CUR)::value ? sB : sA;
+                bb = cs.bb; gbb = cs.gbb; hbb = cs.hbb;
+            }
+            Streamed &cur = decltype(CUR)::value ? sB : sA;
+            auto &b  = [&]() -> VT (&)[NCH] { if constexpr (DMA) return bl;  else return cur.r; }();
+            auto &gb = [&]() -> VT (&)[NCH] { if constexpr (DMA) return gbl; else return cur.g; }();
+            auto &hb = [&]() -> VT (&)[NCH] { if constexpr (DMA) return hbl; else return cur.h; }();
+            if constexpr (FAT) {
+#pragma unroll
+                for (int q = 0; q < NCH; ++q)
+                    if (q == bl_q) {
+                        bb  = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(b[q], 0)), bl_lane));
+                        gbb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(gb[q], 0)), bl_lane));
+                        if constexpr (MOM) hbb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(hb[q], 0)), bl_lane));
+                    }
             }
             // dot product
             float part = 0.0f;
@@ -798,8 +909,14 @@ __global__ __launch_bounds__(256) void k_adagrad_runs(GloveParams p, int32_t n_w
             }
             ++run_len;
             if (last || next_new) close_run();
-            if (deferred) request_streamed();
             open_new = next_new;
+        };
+        constexpr std::integral_constant<int, 0> SET_A{};
+        constexpr std::integral_constant<int, 1> SET_B{};
+        if (n_valid > 0) { decode(0); request_streamed(SET_A, true); request_resident(); }
+        for (int pos = 0; pos < n_valid; pos += 2) {
+            step(pos, SET_A);
+            if (pos + 1 < n_valid) step(pos + 1, SET_B);
         }
     }
     if (lane == 0 && cost_acc != 0.0) atomicAdd(p.cost_out, cost_acc);
