@@ -46,7 +46,10 @@ def kernel_stats(layout):
 
 
 summary = {}
-for layout in ("default", "separate_tables"):
+traffic_entries = []
+for layout in ("default", "separate_tables", "dim100"):
+    if not os.path.exists(os.path.join(src, "bench_%s.json" % layout)):
+        continue
     b = bench_line(os.path.join(src, "bench_%s.json" % layout))
     acc, rows = counters(layout)
     mean = {k: sum(v) / len(v) for k, v in acc.items()}
@@ -79,14 +82,21 @@ for layout in ("default", "separate_tables"):
             with open(os.path.join(out_dir, "r02_bench_pmc_rows.csv"), "w", newline="") as f:
                 w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
         json.dump(s, open(os.path.join(out_dir, "r02_bench_pmc_summary.json"), "w"), indent=1)
-        if "derived" in s and "traffic_bytes_per_launch" in s["derived"]:
-            c = b["config"]
-            json.dump([{"kernel": b["roofline"]["kernel"], "vocab": c["vocab"], "nnz_per_gpu": c["nnz_per_gpu"], "dim": c["dim"], "cost": c["cost"],
-                        "layout": "", "schedule_bytes": b["roofline"]["schedule_bytes_per_launch"],
-                        "traffic_bytes_per_launch": s["derived"]["traffic_bytes_per_launch"],
-                        "source": "profiles/r02_bench_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, FETCH_SIZE x2 per MI355X_MICROARCH.md)"}],
-                      open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
-json.dump(summary, open(os.path.join(out_dir, "r02_layout_evidence.json"), "w"), indent=1)
+    if layout == "dim100":
+        json.dump(s, open(os.path.join(out_dir, "r02_dim100_pmc_summary.json"), "w"), indent=1)
+        ks = kernel_stats(layout)
+        if ks:
+            shutil.copy(ks, os.path.join(out_dir, "r02_dim100_kernel_stats.csv"))
+    if layout in ("default", "dim100") and "derived" in s and "traffic_bytes_per_launch" in s["derived"]:
+        c = b["config"]
+        traffic_entries.append({"kernel": b["roofline"]["kernel"], "vocab": c["vocab"], "nnz_per_gpu": c["nnz_per_gpu"], "dim": c["dim"], "cost": c["cost"],
+                                "layout": "", "schedule_bytes": b["roofline"]["schedule_bytes_per_launch"],
+                                "traffic_bytes_per_launch": s["derived"]["traffic_bytes_per_launch"],
+                                "source": "profiles/r02_%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, FETCH_SIZE x2 per MI355X_MICROARCH.md)"
+                                          % ("bench" if layout == "default" else layout)})
+if traffic_entries:
+    json.dump(traffic_entries, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
+json.dump({k: v for k, v in summary.items() if k != "dim100"}, open(os.path.join(out_dir, "r02_layout_evidence.json"), "w"), indent=1)
 for layout, s in summary.items():
     d = s.get("derived", {})
     print(layout, "kernel_ms", round(s["roofline"]["kernel_ms"], 2), "frac", round(s["roofline"]["frac"], 3), {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}, s["kernel_ms_by_pass"])
