@@ -113,7 +113,7 @@ __device__ __forceinline__ uint16_t bf16_rne(float f) {
     return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 template <bool ROW16>
-__global__ void k_init_java(void *focus_, void *context_, float *fbias, float *cbias, int32_t focus_row0,
+__global__ void k_init_java(void *focus_, void *context_, float *fbias, float *cbias, int64_t bias_stride, int32_t focus_row0,
                             int32_t row0, int32_t rows, int32_t D, int64_t stride, int32_t bias_col, int32_t row_width,
                             uint64_t seed_state, const int32_t *hub_index, float *hub32) {
     const int32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,8 +140,8 @@ __global__ void k_init_java(void *focus_, void *context_, float *fbias, float *c
         }
     }
     if (bias_col < 0) {
-        if (f) fbias[i - focus_row0] = fb;
-        if (c) cbias[i] = cb;
+        if (f) fbias[(i - focus_row0) * bias_stride] = fb;
+        if (c) cbias[i * bias_stride] = cb;
     }
 }
 
@@ -396,13 +396,14 @@ constexpr int KEY_PAD = 0x7FFFFFFF;       // sorts last; marks the unused tail o
 //   publish into with the same atomics as in the fp32 build; they never touch the bf16 table during training.
 template <int VW, int NCH, int OPT, bool EMB16, bool FAT>
 __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD) ? 5 : 1) void k_adagrad_runs(GloveParams p, int32_t n_workers) {
-    static_assert(!(EMB16 && FAT), "bf16 rows keep their biases in separate tables");
     using VT = typename Vec<VW>::T;
     static_assert(!EMB16 || VW == 4, "bf16 embeddings need dim % 4 == 0");
     constexpr bool MOM = OPT != GE_OPT_ADAGRAD;
     // FAT rows (every fp32 Hogwild table): a row is D + 4 floats, element [D] is the row's bias (in the accumulator /
     // moment tables: the bias accumulator / moment), the rest padding that stays zero.  The bias rides in the sector
     // the row's tail already occupies, so a streamed update costs four row accesses and no 4-byte ones.
+    // bf16 rows (EMB16) have no fp32 row to carry the bias: both scalars ride behind the ACCUMULATOR row,
+    // [gradSq (D) | the bias accumulator | the bias | 2 x 0]; the bf16 row itself stays D elements wide.
     // (FAT is chosen on the host: fp32 rows whose bias lane fits the last register chunk -- a dimension that fills its 64-lane
     // chunks exactly would need one more chunk for that one lane and keeps the separate bias tables instead.)
     uint32_t sr_state = 0x9E3779B9u * (uint32_t)(threadIdx.x + 1) + (uint32_t)blockIdx.x * 0x85EBCA6Bu + p.bij_key[0];
@@ -441,6 +442,10 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
     const int32_t DS = p.DS;
     const uint32_t row_bytes = (uint32_t)p.RW * 4u;
     const int bl_q = (D / VW) >> 6, bl_lane = (D / VW) & 63;     // FAT: the lane and register chunk that hold element [D]
+    // FAT: which row (parameter or accumulator) and which component of that lane's vector hold the bias; its accumulator is
+    // component 0 of the accumulator row's lane in both layouts
+    constexpr bool BIAS_IN_ACC = EMB16;
+    constexpr int BIAS_C = EMB16 ? 1 : 0;
     const float lr = p.lr;
     const int wave = rfl((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (wave >= n_workers) return;          // workers pull chunks of the epoch order from one queue
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
         int32_t cur_slot = 0, n_slot = 0;            // EMB16 hub chunk: the row's slot in hub32; else the row id
         auto res_rows = [&](int32_t id, int32_t slot, bool a32) -> __amdgpu_buffer_rsrc_t {
             if constexpr (EMB16) {
-                if (a32) return make_rsrc(p.hub32 + (int64_t)slot * D, row_bytes);
+                if (a32) return make_rsrc(p.hub32 + (int64_t)slot * D, (uint32_t)D * 4u);      // fp32 master rows are plain
                 return make_rsrc(reinterpret_cast<uint16_t *>(A_rows) + (int64_t)id * p.ES, (uint32_t)p.D * 2u);
             } else return make_rsrc(A_rows + (int64_t)id * DS, row_bytes);
         };
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
 #pragma unroll
                     for (int q = 0; q < NCH; ++q)
                         if (q == bl_q && lane == bl_lane) {
-                            if (store_all) comp<VW>(a[q], 0) = ab;
+                            if (store_all) comp<VW>(BIAS_IN_ACC ? ga[q] : a[q], BIAS_C) = ab;
                             comp<VW>(ga[q], 0) = gab;
                             if constexpr (MOM) comp<VW>(ha[q], 0) = hab;
                         }
@@ -638,7 +643,7 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
             // merged last-writer-wins (what the Java race does), written through (sc1) like every table.
             if constexpr (FAT) {
                 if (lane == 0 && !store_all) {             // the rows did not go out whole: the bias slot of each row is stored on its own
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ab), rs_a, D * 4, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, ab), BIAS_IN_ACC ? rs_ga : rs_a, (D + BIAS_C) * 4, 0, AUX_SC1);
                     if (!MOM) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gab), rs_ga, D * 4, 0, AUX_SC1);
                 }
             } else if (lane == 0) {
@@ -788,7 +793,7 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
 #pragma unroll
                     for (int q = 0; q < NCH; ++q)
                         if (q == bl_q) {
-                            ab  = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(a[q], 0)), bl_lane));
+                            ab  = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(BIAS_IN_ACC ? ga[q] : a[q], BIAS_C)), bl_lane));
                             gab = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(ga[q], 0)), bl_lane));
                             if constexpr (MOM) hab = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(ha[q], 0)), bl_lane));
                         }
@@ -831,7 +836,7 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
 #pragma unroll
                 for (int q = 0; q < NCH; ++q)
                     if (q == bl_q) {
-                        bb  = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(b[q], 0)), bl_lane));
+                        bb  = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(BIAS_IN_ACC ? gb[q] : b[q], BIAS_C)), bl_lane));
                         gbb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(gb[q], 0)), bl_lane));
                         if constexpr (MOM) hbb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, comp<VW>(hb[q], 0)), bl_lane));
                     }
@@ -865,7 +870,8 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
                 if (inr[q] || is_bl) {
                     VT ob{}, ogb{}, ohb{};
                     if (is_bl) {
-                        comp<VW>(ob, 0) = nbb_fat; comp<VW>(ogb, 0) = ngbb_fat; comp<VW>(ohb, 0) = nhbb_fat;
+                        comp<VW>(ogb, 0) = ngbb_fat; comp<VW>(ohb, 0) = nhbb_fat;
+                        comp<VW>(BIAS_IN_ACC ? ogb : ob, BIAS_C) = nbb_fat;     // (bf16: this lane's row store lies past the bf16 row and is dropped)
                     } else {
 #pragma unroll
                         for (int t = 0; t < VW; ++t) {
@@ -935,12 +941,13 @@ hogwild_fn pick_nch(int nch) {
         default: return nullptr;
     }
 }
+template <bool FAT>
 hogwild_fn pick_bf16(int nch) {       // bf16 embeddings: AdaGrad, dim % 4 == 0
     switch (nch) {
-        case 1: return k_adagrad_runs<4, 1, GE_OPT_ADAGRAD, true, false>;
-        case 2: return k_adagrad_runs<4, 2, GE_OPT_ADAGRAD, true, false>;
-        case 3: return k_adagrad_runs<4, 3, GE_OPT_ADAGRAD, true, false>;
-        case 4: return k_adagrad_runs<4, 4, GE_OPT_ADAGRAD, true, false>;
+        case 1: return k_adagrad_runs<4, 1, GE_OPT_ADAGRAD, true, FAT>;
+        case 2: return k_adagrad_runs<4, 2, GE_OPT_ADAGRAD, true, FAT>;
+        case 3: return k_adagrad_runs<4, 3, GE_OPT_ADAGRAD, true, FAT>;
+        case 4: return k_adagrad_runs<4, 4, GE_OPT_ADAGRAD, true, FAT>;
         default: return nullptr;
     }
 }
@@ -948,14 +955,15 @@ template <int OPT, bool FAT>
 hogwild_fn pick_vw(int vw, int nch) { return vw == 4 ? pick_nch<4, OPT, FAT>(nch) : vw == 2 ? pick_nch<2, OPT, FAT>(nch) : pick_nch<1, OPT, FAT>(nch); }
 template <int OPT>
 hogwild_fn pick_fat(int vw, int nch, bool fat) { return fat ? pick_vw<OPT, true>(vw, nch) : pick_vw<OPT, false>(vw, nch); }
-// fp32 rows carry their bias at element [D] (fat rows) when the lane that would hold it lies in the row's last 64-lane chunk
+// rows carry their bias at element [D] (fat rows; bf16 rows: behind the accumulator row) when the lane that would hold it lies in
+// the row's last 64-lane chunk
 inline bool fat_rows_fit(int D) { const int vw = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1; return ((D / vw) % 64) != 0; }
 // One wavefront spans a row: 64 lanes x VW floats x NCH chunks >= D.
 hogwild_fn pick_hogwild(int D, int opt, bool emb16, int *vw_out, int *nch_out) {
     const int vw = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
-    const bool fat = !emb16 && fat_rows_fit(D);
+    const bool fat = fat_rows_fit(D);
     const int nch = (D + 64 * vw - 1) / (64 * vw);           // the bias lane of a fat row lies inside the last chunk
-    hogwild_fn fn = emb16 ? pick_bf16(nch)
+    hogwild_fn fn = emb16 ? (fat ? pick_bf16<true>(nch) : pick_bf16<false>(nch))
                   : opt == GE_OPT_ADAGRAD ? pick_fat<GE_OPT_ADAGRAD>(vw, nch, fat)
                   : opt == GE_OPT_ADAM ? pick_fat<GE_OPT_ADAM>(vw, nch, fat) : pick_fat<GE_OPT_AMSGRAD>(vw, nch, fat);
     *vw_out = vw; *nch_out = nch;
@@ -1087,6 +1095,26 @@ void ge_glove_cfg_default(ge_glove_cfg *cfg) {
     cfg->shuffle = GE_SHUFFLE_DEVICE;
 }
 
+// Where the API's table `which` lives on the device.  Fat handles keep no bias tables: an fp32 row carries its bias at column
+// [dim] (and the accumulator / moment row the bias's accumulator / moment there); a bf16 handle's rows cannot, so both scalars sit
+// behind the ACCUMULATOR row: [gradSq (dim) | the bias accumulator | the bias | 2 x 0].
+static const int FAT_HOME[GE_STATE_COUNT] = {GE_STATE_FOCUS, GE_STATE_CONTEXT, GE_STATE_FOCUS, GE_STATE_CONTEXT,
+                                             GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_CONTEXT,
+                                             GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT};
+static bool is_bias_table(int which) { return FAT_HOME[which] != which; }
+struct Home { float *base; int32_t col0, ncols; int64_t stride; };       // table[r][c] = base[r * stride + col0 + c], c < ncols
+static Home home_of(const ge_glove *h, int which) {
+    const int32_t D = h->cfg.dim;
+    if (!is_bias_table(which)) return {h->tab[which], 0, D, h->ds};
+    if (!h->fat) return {h->tab[which], 0, 1, 1};
+    if (h->emb16) {
+        const bool focus_side = which == GE_STATE_FBIAS || which == GE_STATE_GSQ_FBIAS;
+        const bool the_bias = which == GE_STATE_FBIAS || which == GE_STATE_CBIAS;
+        return {h->tab[focus_side ? GE_STATE_GSQ_FOCUS : GE_STATE_GSQ_CONTEXT], the_bias ? D + 1 : D, 1, h->ds};
+    }
+    return {h->tab[FAT_HOME[which]], D, 1, h->ds};
+}
+
 static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I, const int32_t *J, const float *X,
                           ge_glove **out) {
     if (!out) return ge::fail(GE_ERR_ARG, "out is null");
@@ -1128,7 +1156,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     if (!h) return ge::fail(GE_ERR_OOM, "host allocation failed");
     h->cfg = *cfg;
     h->emb16 = emb16;
-    h->fat = cfg->mode == GE_MODE_HOGWILD && !emb16 && fat_rows_fit(cfg->dim);
+    h->fat = cfg->mode == GE_MODE_HOGWILD && fat_rows_fit(cfg->dim);
     h->cfg.row_begin = rb; h->cfg.row_end = re;
     h->rows = re - rb;
     h->stream = (hipStream_t)cfg->stream;
@@ -1140,7 +1168,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     h->ds = h->rw * (interleave ? (moments ? 3 : 2) : 1);
     // bf16 rows in records: [bf16 row, padded to 16 bytes | fp32 accumulator row]; e16 = bf16 elements of the padded row
     const int32_t e16 = (D + 7) / 8 * 8;
-    if (emb16) { h->ds = interleave ? e16 / 2 + D : D; h->es = interleave ? 2 * h->ds : D; }
+    if (emb16) { h->ds = interleave ? e16 / 2 + h->rw : h->rw; h->es = interleave ? 2 * h->ds : D; }      // rw: the accumulator row (fat: + its two scalars)
 
     // every failure below frees what the handle owns so far (ge_glove_destroy walks h->owned)
 #define GE_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ge_status _s = ge::fail(_e == hipErrorOutOfMemory ? GE_ERR_OOM : GE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); ge_glove_destroy(h); return _s; } } while (0)
@@ -1151,8 +1179,8 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
 
     // ---- tables, allocated once, in their final layout ------------------------------------------------------------
     // fp32 row tables: `rw` floats per row (fat rows carry the bias at [D]); unless GE_LAYOUT_SEPARATE_TABLES a side is ONE
-    // allocation of records [row | accumulator row (| second moment row)], stride ds = 2 or 3 rw.  bf16 rows: dense
-    // [rows x D] bf16 tables, fp32 accumulators, separate bias vectors.
+    // allocation of records [row | accumulator row (| second moment row)], stride ds = 2 or 3 rw.  bf16 rows: records
+    // [bf16 row padded to 16 bytes | fp32 accumulator row, fat: gradSq (D) | its bias accumulator | the bias | 2 x 0].
     const int64_t counts[GE_STATE_COUNT] = {
         (int64_t)h->rows * D, (int64_t)V * D, h->rows, V, (int64_t)h->rows * D, (int64_t)V * D, h->rows, V,
         moments ? (int64_t)h->rows * D : 0, moments ? (int64_t)V * D : 0, moments ? h->rows : 0, moments ? V : 0};
@@ -1277,19 +1305,8 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
         GE_TRY(h->alloc(&h->hub32, (size_t)std::max<int64_t>((int64_t)h->n_hub * D, 1)));
     }
     {
-        const int64_t stride = emb16 ? h->es : h->ds;
-        const int32_t bias_col = h->fat ? D : -1;
-        void *foc = h->tab[GE_STATE_FOCUS], *ctx = h->tab[GE_STATE_CONTEXT];
-        auto launch = [&](void *f, void *c, int32_t row0, int32_t nrows) {
-            const dim3 g((unsigned)((nrows + 127) / 128)), b(128);
-            if (emb16) hipLaunchKernelGGL(k_init_java<true>, g, b, 0, h->stream, f, c, h->tab[GE_STATE_FBIAS], h->tab[GE_STATE_CBIAS], rb,
-                                          row0, nrows, D, stride, bias_col, h->rw, s0, (const int32_t *)h->dhub_index, h->hub32);
-            else hipLaunchKernelGGL(k_init_java<false>, g, b, 0, h->stream, f, c, h->tab[GE_STATE_FBIAS], h->tab[GE_STATE_CBIAS], rb,
-                                    row0, nrows, D, stride, bias_col, h->rw, s0, (const int32_t *)nullptr, (float *)nullptr);
-        };
-        if (h->rows == V) launch(foc, ctx, 0, V);
-        else { launch(nullptr, ctx, 0, V); launch(foc, nullptr, rb, h->rows); }
-        // Adagrad ctor: gradSq = 1 (Adagrad.java:27-33); Adam / AMSGrad ctors: every moment = 0 (new float[])
+        // Adagrad ctor: gradSq = 1 (Adagrad.java:27-33); Adam / AMSGrad ctors: every moment = 0 (new float[]).  Before the parameter
+        // init: a bf16 handle's bias lives in the accumulator row and must survive the fill.
         const float v0 = moments ? 0.0f : 1.0f;
         for (int t : {GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_CONTEXT, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT}) {
             if (!h->tab[t]) continue;
@@ -1302,6 +1319,19 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
             const int64_t n = h->tab_count[t];
             hipLaunchKernelGGL(k_fill, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 4096))), dim3(256), 0, h->stream, h->tab[t], n, v0);
         }
+        const int64_t stride = emb16 ? h->es : h->ds;
+        const int32_t bias_col = (h->fat && !emb16) ? D : -1;        // fp32 fat rows: the bias is a column of the row being written
+        const Home fb = home_of(h, GE_STATE_FBIAS), cb = home_of(h, GE_STATE_CBIAS);
+        void *foc = h->tab[GE_STATE_FOCUS], *ctx = h->tab[GE_STATE_CONTEXT];
+        auto launch = [&](void *f, void *c, int32_t row0, int32_t nrows) {
+            const dim3 g((unsigned)((nrows + 127) / 128)), b(128);
+            if (emb16) hipLaunchKernelGGL(k_init_java<true>, g, b, 0, h->stream, f, c, fb.base + fb.col0, cb.base + cb.col0, (int64_t)fb.stride, rb,
+                                          row0, nrows, D, stride, bias_col, h->rw, s0, (const int32_t *)h->dhub_index, h->hub32);
+            else hipLaunchKernelGGL(k_init_java<false>, g, b, 0, h->stream, f, c, fb.base ? fb.base + fb.col0 : nullptr, cb.base ? cb.base + cb.col0 : nullptr, (int64_t)fb.stride, rb,
+                                    row0, nrows, D, stride, bias_col, h->rw, s0, (const int32_t *)nullptr, (float *)nullptr);
+        };
+        if (h->rows == V) launch(foc, ctx, 0, V);
+        else { launch(nullptr, ctx, 0, V); launch(foc, nullptr, rb, h->rows); }
     }
     GE_TRY(hipGetLastError());
     GE_TRY(hipStreamSynchronize(h->stream));
@@ -1368,10 +1398,6 @@ static ge_status ge_glove_epoch_impl(ge_glove *h, int32_t iteration, double *cos
 
 // bf16 build: an fp32 device copy of FOCUS or CONTEXT as the caller sees it (hub rows from their fp32 masters)
 // fat build: any table as the API shows it (rows [n x D] or a bias vector [n]) gathered out of the fat rows
-static const int FAT_HOME[GE_STATE_COUNT] = {GE_STATE_FOCUS, GE_STATE_CONTEXT, GE_STATE_FOCUS, GE_STATE_CONTEXT,
-                                             GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FOCUS, GE_STATE_GSQ_CONTEXT,
-                                             GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT};
-static bool is_bias_table(int which) { return FAT_HOME[which] != which; }
 // does the API view of table `which` differ from how the handle stores it?  (fat rows: every fp32 table; interleaved
 // records: the row tables; bf16: the two embedding tables)
 static bool stored_strided(const ge_glove *h, int which) {
@@ -1383,11 +1409,9 @@ static ge_status materialize_f32(ge_glove *h, int which, float **out) {
     float *d = nullptr;
     GE_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)std::max<int64_t>(n, 1)));
     if (stored_strided(h, which)) {
-        const bool bias = is_bias_table(which);
-        const int32_t D = h->cfg.dim;
-        const int64_t rows = bias ? n : n / D;
+        const Home hm = home_of(h, which);
         hipLaunchKernelGGL(k_fat_gather, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n + 255) / 256, 16384))), dim3(256), 0, h->stream,
-                           h->tab[FAT_HOME[which]], rows, h->ds, bias ? D : 0, bias ? 1 : D, d);
+                           hm.base, n / hm.ncols, (int32_t)hm.stride, hm.col0, hm.ncols, d);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { (void)hipFree(d); return ge::fail(GE_ERR_HIP, "row gather failed: %s", hipGetErrorString(e)); }
         *out = d;
@@ -1467,10 +1491,9 @@ ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_
         GE_HIP(hipMalloc((void **)&d, sizeof(float) * (size_t)count));
         hipError_t e = hipMemcpyAsync(d, in, sizeof(float) * (size_t)count, hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess) {
-            const bool bias = is_bias_table(which);
-            const int32_t D = h->cfg.dim;
+            const Home hm = home_of(h, which);
             hipLaunchKernelGGL(k_fat_scatter, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 16384))), dim3(256), 0, h->stream,
-                               h->tab[FAT_HOME[which]], bias ? count : count / D, h->ds, bias ? D : 0, bias ? 1 : D, d);
+                               hm.base, count / hm.ncols, (int32_t)hm.stride, hm.col0, hm.ncols, d);
             e = hipGetLastError();
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         }
@@ -1504,11 +1527,12 @@ ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *
     if (h->emb16 && (which == GE_STATE_FOCUS || which == GE_STATE_CONTEXT))
         return ge::fail(GE_ERR_STATE, "table %d is stored as bf16 (+ fp32 hub rows); use ge_glove_get_state/set_state", which);
     if (stored_strided(h, which)) {
-        // fat rows: a row table is [n x row_stride] with the bias at column dim; a bias "table" is that column of its home
-        // table.  *count = floats from the returned pointer to the end of the last row ((n - 1) * row_stride + row width).
-        *dptr = h->tab[FAT_HOME[which]];
-        const int64_t nr = is_bias_table(which) ? h->tab_count[which] : h->tab_count[which] / h->cfg.dim;
-        if (count) *count = nr > 0 ? (nr - 1) * (int64_t)h->ds + h->rw : 0;
+        // a row table is [n x row_stride]; a bias "table" is one column of its home table (home_of): the pointer is row 0's
+        // scalar, consecutive rows are row_stride floats apart.  *count = floats from the returned pointer to the end of the last row's part.
+        const Home hm = home_of(h, which);
+        *dptr = hm.base + hm.col0;
+        const int64_t nr = h->tab_count[which] / hm.ncols;
+        if (count) *count = nr > 0 ? (nr - 1) * hm.stride + (is_bias_table(which) ? 1 : h->rw) : 0;
         return GE_OK;
     }
     *dptr = h->tab[which];
@@ -1527,6 +1551,9 @@ ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out) {
     out->row_stride = h->emb16 ? h->es : h->ds;
     out->accum = h->tab[GE_STATE_GSQ_CONTEXT];
     out->accum_stride = h->ds;
+    const Home cb = home_of(h, GE_STATE_CBIAS), gcb = home_of(h, GE_STATE_GSQ_CBIAS);
+    out->bias = cb.base + cb.col0; out->bias_stride = (int32_t)cb.stride;
+    out->accum_bias = gcb.base + gcb.col0; out->accum_bias_stride = (int32_t)gcb.stride;
     return GE_OK;
 }
 

@@ -30,7 +30,6 @@
 #include <vector>
 
 // glove.hip
-extern "C" ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *count);
 namespace ge { ge_status glove_sync_view(ge_glove *h, int32_t *opt, int32_t *mode, void **stream, int32_t *device); }
 
 namespace {
@@ -457,9 +456,6 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
     if (st != GE_OK) { ge_sync_destroy(s); return st; }
     const int64_t V = s->lay.vocab_size; const int32_t D = s->lay.dim;
     const bool w16 = cfg->wire == GE_DTYPE_BF16;
-    void *p_cb = nullptr, *p_gcb = nullptr; int64_t cnt = 0;
-    if ((st = ge_glove_device_ptr(h, GE_STATE_CBIAS, &p_cb, &cnt)) != GE_OK || (st = ge_glove_device_ptr(h, GE_STATE_GSQ_CBIAS, &p_gcb, &cnt)) != GE_OK) { ge_sync_destroy(s); return st; }
-    const bool bias_in_row = s->lay.dtype == GE_DTYPE_F32 && p_cb == s->lay.table;     // fat rows: the bias is column [dim] of its row
     auto add = [&](const char *name, float *table, int64_t stride, int32_t cols, bool mean, bool lazy, bool narrow) {
         Entry e; e.name = name; e.table = table; e.t_stride = stride; e.cols = cols; e.rows = V; e.n = V * cols;
         e.mean = mean; e.lazy = lazy; e.w16 = narrow && !mean;
@@ -469,9 +465,10 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
         add("context rows (bf16)", nullptr, D, D, false, false, true);
         s->ent.back().bf16_rows = true;
     } else add("context rows", (float *)s->lay.table, s->lay.row_stride, D, false, false, w16);
-    add("cBias", bias_in_row ? (float *)s->lay.table + D : (float *)p_cb, bias_in_row ? s->lay.row_stride : 1, 1, true, false, false);
+    // the two scalars of a row, wherever the handle keeps them (a vector, a column of the fat row, columns behind the accumulator row)
+    add("cBias", s->lay.bias, s->lay.bias_stride, 1, true, false, false);
     add("gradSqContext", s->lay.accum, s->lay.accum_stride, D, false, true, w16);
-    add("gradSqCBias", bias_in_row ? s->lay.accum + D : (float *)p_gcb, bias_in_row ? s->lay.accum_stride : 1, 1, false, true, false);
+    add("gradSqCBias", s->lay.accum_bias, s->lay.accum_bias_stride, 1, false, true, false);
     if (cfg->world > 1) {
         for (Entry &e : s->ent) {
             GE_TRYS(s->alloc(&e.base, (size_t)e.n));

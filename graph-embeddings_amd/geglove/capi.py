@@ -81,7 +81,8 @@ class Strings(C.Structure):
 class ContextLayout(C.Structure):
     _fields_ = [("table", C.c_void_p), ("dtype", C.c_int32), ("hub_rows", C.c_void_p), ("hub_index", C.c_void_p),
                 ("n_hub", C.c_int32), ("vocab_size", C.c_int32), ("dim", C.c_int32), ("row_stride", C.c_int32), ("accum", C.c_void_p),
-                ("accum_stride", C.c_int32)]
+                ("accum_stride", C.c_int32), ("bias", C.c_void_p), ("bias_stride", C.c_int32), ("accum_bias", C.c_void_p),
+                ("accum_bias_stride", C.c_int32)]
 
 
 TRANSPORT_START = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p))

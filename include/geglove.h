@@ -206,8 +206,10 @@ ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_
  * GE_MODE_DETERMINISTIC handles: the table as the API shows it, *count floats.  GE_MODE_HOGWILD handles with fp32 rows keep
  * FAT rows (row width dim + 4, a row's bias at [dim]) inside records of ge_context_layout.row_stride floats (row | accumulator
  * row | ...): a row table id returns the address of ITS row in the first record and *count = the floats from there to the end
- * of its row in the last record; a bias table id returns the row table it lives in (FBIAS -> FOCUS, GSQ_CBIAS -> GSQ_CONTEXT
- * ...), the bias of row r being element r * row_stride + dim.  bf16 row tables are refused (ge_glove_context_layout). */
+ * of its row in the last record; a bias table id returns the address of row 0's scalar inside the row that carries it (FBIAS ->
+ * column [dim] of FOCUS, GSQ_CBIAS -> column [dim] of GSQ_CONTEXT ...; with bf16 rows both scalars follow the accumulator row:
+ * GSQ_*BIAS at its column [dim], *BIAS at [dim + 1]), the scalar of row r being element r * row_stride from there (row_stride:
+ * ge_glove_info.row_stride floats).  bf16 row tables are refused (ge_glove_context_layout). */
 ge_status ge_glove_device_ptr(ge_glove *h, int32_t which, void **dptr, int64_t *count);
 
 /* The order in which ONE worker (cfg.workers = 1) walks the nonzeros in epoch `iteration` of a HOGWILD handle:
@@ -340,10 +342,16 @@ typedef struct {
     int32_t        n_hub, vocab_size, dim;
     int32_t        row_stride;   /* elements of `table`'s dtype between consecutive rows of `table`.  fp32 GE_MODE_HOGWILD handles keep
                                     FAT rows (width dim + 4, a row's bias at [dim]) inside records [row | accumulator row]: row_stride =
-                                    2 (dim + 4) floats; bf16 rows lead records [bf16 row padded to 16 B | fp32 accumulator row]:
-                                    row_stride = that record in bf16 elements; GE_LAYOUT_SEPARATE_TABLES: the row width itself */
+                                    2 (dim + 4) floats; bf16 rows lead records [bf16 row padded to 16 B | fp32 accumulator row, fat:
+                                    gradSq (dim) | its bias accumulator | the bias | 2 x 0]: row_stride = that record in bf16
+                                    elements; GE_LAYOUT_SEPARATE_TABLES: the row width itself */
     float         *accum;        /* gradSqContext (Adam/AMSGrad: M1context); fp32 always; fat like `table` when that is fp32 */
     int32_t        accum_stride; /* floats between consecutive rows of `accum` (its bias accumulator at [dim] when fat)             */
+    float         *bias;         /* cBias[v] = bias[v * bias_stride]: a vector of its own (stride 1), column [dim] of the fat fp32 row,
+                                    or -- bf16 rows, which cannot carry it -- column [dim + 1] of the accumulator row                */
+    int32_t        bias_stride;
+    float         *accum_bias;   /* gradSqCBias[v] = accum_bias[v * accum_bias_stride] (fat: column [dim] of the accumulator row)      */
+    int32_t        accum_bias_stride;
 } ge_context_layout;
 ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out);
 
