@@ -867,11 +867,14 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
             for (int q = 0; q < NCH; ++q) {
                 // one store instruction per table covers the row's lanes AND the lane that holds the bias
                 const bool is_bl = FAT && q == bl_q && lane == bl_lane;
-                if (inr[q] || is_bl) {
+                const bool tail = FAT && !inr[q] && (lane + q * 64) * VW < p.RW;     // the bias lane and the padding behind it: stored too, whole lines go out
+                if (inr[q] || tail) {
                     VT ob{}, ogb{}, ohb{};
-                    if (is_bl) {
-                        comp<VW>(ogb, 0) = ngbb_fat; comp<VW>(ohb, 0) = nhbb_fat;
-                        comp<VW>(BIAS_IN_ACC ? ogb : ob, BIAS_C) = nbb_fat;     // (bf16: this lane's row store lies past the bf16 row and is dropped)
+                    if (tail) {
+                        if (is_bl) {
+                            comp<VW>(ogb, 0) = ngbb_fat; comp<VW>(ohb, 0) = nhbb_fat;
+                            comp<VW>(BIAS_IN_ACC ? ogb : ob, BIAS_C) = nbb_fat;     // (bf16: this lane's row store lies past the bf16 row and is dropped)
+                        }
                     } else {
 #pragma unroll
                         for (int t = 0; t < VW; ++t) {
@@ -1137,7 +1140,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     if (emb16 && (cfg->mode != GE_MODE_HOGWILD || cfg->shuffle != GE_SHUFFLE_DEVICE || cfg->opt != GE_OPT_ADAGRAD || cfg->dim % 4 != 0))
         return ge::fail(GE_ERR_ARG, "bf16 embeddings need mode=hogwild, shuffle=device, opt=adagrad and dim %% 4 == 0 (the reference path is fp32)");
     if (cfg->hot_columns < GE_HOT_AUTO || cfg->hot_columns > GE_HOT_ALL) return ge::fail(GE_ERR_ARG, "invalid hot_columns %d", cfg->hot_columns);
-    if (cfg->hot_theta < 0 || cfg->stale_budget < 0 || cfg->flush_every < 0 || cfg->blocks_per_cu < 0 || (cfg->layout_flags & ~7) != 0)
+    if (cfg->hot_theta < 0 || cfg->stale_budget < 0 || cfg->flush_every < 0 || cfg->blocks_per_cu < 0 || (cfg->layout_flags & ~15) != 0)
         return ge::fail(GE_ERR_ARG, "invalid tuning fields (hot_theta %g, stale_budget %g, flush_every %d, blocks_per_cu %d, layout_flags %d)",
                         (double)cfg->hot_theta, (double)cfg->stale_budget, cfg->flush_every, cfg->blocks_per_cu, cfg->layout_flags);
     int32_t rb = cfg->row_begin, re = cfg->row_end;
@@ -1164,11 +1167,26 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     const int64_t N = cfg->nnz;
     const bool moments = cfg->opt != GE_OPT_ADAGRAD;      // Adam / AMSGrad keep M2* next to M1*
     const bool interleave = cfg->mode == GE_MODE_HOGWILD && (cfg->layout_flags & GE_LAYOUT_SEPARATE_TABLES) == 0;
+    const bool packed = (cfg->layout_flags & GE_LAYOUT_PACKED_RECORDS) != 0;
     h->rw = h->fat ? D + 4 : D;
+    // An fp32 fat row as wide as the whole 64-byte lines that hold it (D = 200: 208 floats): every row store then writes whole
+    // lines and a row shares no line with its accumulator row.  More bytes, less time: D = 100 (112 instead of 104 floats) 29.8 /
+    // 30.4 -> 27.5 / 27.5 ms, D = 200 48.9 / 53.8 -> 47.8 / 47.8 ms (tools/r02/rw_probe.sh).  Not for bf16 rows (no
+    // gain measured) and not where the padding would exceed 10 %.
+    if (h->fat && !emb16 && !packed && D % 4 == 0) {
+        const int32_t lines = (D + 1 + 15) / 16 * 16;
+        if ((int64_t)lines * 10 <= (int64_t)(D + 4) * 11) h->rw = lines;
+    }
     h->ds = h->rw * (interleave ? (moments ? 3 : 2) : 1);
     // bf16 rows in records: [bf16 row, padded to 16 bytes | fp32 accumulator row]; e16 = bf16 elements of the padded row
     const int32_t e16 = (D + 7) / 8 * 8;
-    if (emb16) { h->ds = interleave ? e16 / 2 + h->rw : h->rw; h->es = interleave ? 2 * h->ds : D; }      // rw: the accumulator row (fat: + its two scalars)
+    if (emb16) h->ds = interleave ? e16 / 2 + h->rw : h->rw;                                             // rw: the accumulator row (fat: + its two scalars)
+    // A record starts on a 64-byte boundary: a wave's 16-byte-per-lane row access then covers whole 64-byte requests.  Records of
+    // 1 632 bytes (D = 200) start on odd 32-byte sectors half of the time; rounding them up to 1 664 took the epoch from 60.9 to
+    // 49.2 ms on one box and from 60.8 to 54.6 on another (tools/r02/align_probe.sh, kernel_ab.sh).  Rounding further
+    // (128 bytes and more) gains nothing at D = 200 and loses 5 % on the 1 216-byte records of bf16 rows.  The padding is never touched.
+    if (interleave && !packed) h->ds = (h->ds + 15) / 16 * 16;
+    if (emb16) h->es = interleave ? 2 * h->ds : D;
 
     // every failure below frees what the handle owns so far (ge_glove_destroy walks h->owned)
 #define GE_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ge_status _s = ge::fail(_e == hipErrorOutOfMemory ? GE_ERR_OOM : GE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); ge_glove_destroy(h); return _s; } } while (0)
@@ -1628,7 +1646,8 @@ ge_status ge_glove_get_info(ge_glove *h, ge_glove_info *info) {
     info->flush_min = h->flush_every; info->row_stride = h->ds;
     if (h->blocked) {
         // one row access = the bytes a wavefront's row instruction moves: the row width of the table it touches
-        const int64_t emb = h->emb16 ? 2ll * h->cfg.dim : 4ll * h->rw, acc = 4ll * h->rw;
+        // (the row as the update needs it: dim + 4 floats when fat; what the line-aligned layout pads it with is not counted)
+        const int64_t acc = 4ll * (h->cfg.dim + (h->fat ? 4 : 0)), emb = h->emb16 ? 2ll * h->cfg.dim : acc;
         const int64_t aux = h->cfg.opt == GE_OPT_ADAGRAD ? 1 : 2;                 // accumulator rows per side
         const int64_t pair = 2 * (emb + aux * acc) + (h->fat ? 0 : 2 * 4 * (1 + aux));   // load + store of a row, its accumulator row(s) and, unless fat, its scalars
         info->runs = h->lay.n_runs;

@@ -18,7 +18,7 @@ GE_MODE_HOGWILD, GE_MODE_DETERMINISTIC = 0, 1
 GE_SHUFFLE_JAVA, GE_SHUFFLE_DEVICE, GE_SHUFFLE_NONE = 0, 1, 2
 GE_HOT_AUTO, GE_HOT_NONE, GE_HOT_ALL = 0, 1, 2
 GE_DTYPE_F32, GE_DTYPE_BF16 = 0, 1
-GE_LAYOUT_FIXED_CUTS, GE_LAYOUT_PLAIN_LONG_ROWS, GE_LAYOUT_SEPARATE_TABLES = 1, 2, 4
+GE_LAYOUT_FIXED_CUTS, GE_LAYOUT_PLAIN_LONG_ROWS, GE_LAYOUT_SEPARATE_TABLES, GE_LAYOUT_PACKED_RECORDS = 1, 2, 4, 8
 (GE_STATE_FOCUS, GE_STATE_CONTEXT, GE_STATE_FBIAS, GE_STATE_CBIAS, GE_STATE_GSQ_FOCUS,
  GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FBIAS, GE_STATE_GSQ_CBIAS, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT,
  GE_STATE_M2_FBIAS, GE_STATE_M2_CBIAS) = range(12)

@@ -251,7 +251,7 @@ struct Configuration {
     // new, optional block `device:` (never changes the meaning of a reference key)
     struct { std::string mode = "hogwild", shuffle = "device", hot = "auto", dtype = "f32", save_coo, load_coo;
              long long seed = 0; bool has_seed = false; int id = 0; int workers = 0;
-             // Hogwild tuning (ge_glove_cfg: 0 = library default), layout: list of fixed_cuts | plain_long_rows | separate_tables
+             // Hogwild tuning (ge_glove_cfg: 0 = library default), layout: list of fixed_cuts | plain_long_rows | separate_tables | packed_records
              double hot_theta = 0, stale_budget = 0; int flush_every = 0, blocks_per_cu = 0, layout_flags = 0;
              long long bca_table_slots = 0, bca_pool_entries = 0;
              // multi-GPU: gpus ranks, one thread each, rows sharded, context exchanged through ge_sync
@@ -360,6 +360,7 @@ struct Configuration {
                             if (nm == "fixed_cuts") c.device.layout_flags |= GE_LAYOUT_FIXED_CUTS;
                             else if (nm == "plain_long_rows") c.device.layout_flags |= GE_LAYOUT_PLAIN_LONG_ROWS;
                             else if (nm == "separate_tables") c.device.layout_flags |= GE_LAYOUT_SEPARATE_TABLES;
+                            else if (nm == "packed_records") c.device.layout_flags |= GE_LAYOUT_PACKED_RECORDS;
                             else if (!nm.empty() && nm != "default") throw std::invalid_argument("device.layout: unknown flag " + nm);
                         }
                     }

@@ -150,8 +150,12 @@ typedef struct {
  * SEPARATE_TABLES  round-1 storage: a table per kind.  Default (fp32 rows): a side's row and its accumulator row (and
  *                second-moment row) are ONE record of 2 (3) x row width floats, so the loads / stores of one update touch
  *                one region per side instead of two -- measured 7 % faster in alternation and free of the slow placements
- *                separate tables fall into -- ablation / tests. */
-enum { GE_LAYOUT_FIXED_CUTS = 1, GE_LAYOUT_PLAIN_LONG_ROWS = 2, GE_LAYOUT_SEPARATE_TABLES = 4 };
+ *                separate tables fall into -- ablation / tests.
+ * PACKED_RECORDS  fat rows exactly dim + 4 floats wide and records back to back, as before the alignment work.  Default:
+ *                records start on 64-byte boundaries, and an fp32 row with dim % 4 == 0 is as wide as the whole 64-byte lines
+ *                that hold dim + 1 floats (dim 200: 208; skipped where that would add more than 10 %), so every row store writes
+ *                whole lines and a row shares no line with its accumulator row -- ablation / tests. */
+enum { GE_LAYOUT_FIXED_CUTS = 1, GE_LAYOUT_PLAIN_LONG_ROWS = 2, GE_LAYOUT_SEPARATE_TABLES = 4, GE_LAYOUT_PACKED_RECORDS = 8 };
 
 /* What the library decided for a handle (reporting / DESIGN.md numbers). */
 typedef struct {
