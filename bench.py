@@ -214,7 +214,7 @@ def main():
         info = opt.info()
         kernel = "k_adagrad_runs<%d, %d, %s, %s, %s>" % (info["vector_width"], info["chunks_per_lane"], {"adagrad": 0, "adam": 1, "amsgrad": 2}[args.opt],
                                                           "true" if args.dtype == "bf16" else "false",
-                                                          "true" if (args.dtype != "bf16" and (D // info["vector_width"]) % 64 != 0) else "false")
+                                                          "true" if (D // info["vector_width"]) % 64 != 0 else "false")     # fat rows (bf16: fat accumulator rows)
         # HBM traffic per launch from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the gfx950 correction +
         # WRITE_SIZE); an entry counts only for the kernel instance, workload and layout it was taken on
         traffic = None
@@ -222,8 +222,8 @@ def main():
         if os.path.exists(tpath) and world == 1:
             try:
                 for t in json.load(open(tpath)):
-                    if (t.get("kernel"), t["vocab"], t["nnz_per_gpu"], t["dim"], t["cost"], t.get("layout", ""), t.get("schedule_bytes")) == \
-                            (kernel, V, n_local, D, args.method, args.layout, info["schedule_bytes"]):
+                    if (t.get("kernel"), t["vocab"], t["nnz_per_gpu"], t["dim"], t["cost"], t.get("layout", ""), t.get("schedule_bytes"), t.get("row_stride")) == \
+                            (kernel, V, n_local, D, args.method, args.layout, info["schedule_bytes"], info["row_stride"]):
                         traffic = t["traffic_bytes_per_launch"]
             except Exception:
                 traffic = None

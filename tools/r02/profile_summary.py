@@ -47,7 +47,7 @@ def kernel_stats(layout):
 
 summary = {}
 traffic_entries = []
-for layout in ("default", "separate_tables", "dim100"):
+for layout in ("default", "separate_tables", "packed_records", "dim100"):
     if not os.path.exists(os.path.join(src, "bench_%s.json" % layout)):
         continue
     b = bench_line(os.path.join(src, "bench_%s.json" % layout))
@@ -90,7 +90,7 @@ for layout in ("default", "separate_tables", "dim100"):
     if layout in ("default", "dim100") and "derived" in s and "traffic_bytes_per_launch" in s["derived"]:
         c = b["config"]
         traffic_entries.append({"kernel": b["roofline"]["kernel"], "vocab": c["vocab"], "nnz_per_gpu": c["nnz_per_gpu"], "dim": c["dim"], "cost": c["cost"],
-                                "layout": "", "schedule_bytes": b["roofline"]["schedule_bytes_per_launch"],
+                                "layout": "", "schedule_bytes": b["roofline"]["schedule_bytes_per_launch"], "row_stride": b["trainer"]["row_stride"],
                                 "traffic_bytes_per_launch": s["derived"]["traffic_bytes_per_launch"],
                                 "source": "profiles/r02_%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE, FETCH_SIZE x2 per MI355X_MICROARCH.md)"
                                           % ("bench" if layout == "default" else layout)})
