@@ -1,6 +1,8 @@
 #!/bin/bash
 # Does the start alignment of a record (row | accumulator row) and of the accumulator row inside it matter?  Probe build:
 # GE_PROBE_ROW_ALIGN = offset of the accumulator row rounded up to that many floats, GE_PROBE_RECORD_ALIGN = record stride likewise.
+# (The probe build was glove.hip with two getenv lines in ge_glove_create_impl -- `ds` and the accumulator row's offset rounded up to the
+# given number of floats -- linked as tools/r02/_ab/libgeglove_align.so; not kept: the result became the default layout.)
 # Fresh process per run, alternating.   CASES: "rowalign:recalign" pairs.
 mkdir -p gpurun_out/r02
 OUT=gpurun_out/r02/align_probe.log

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Row width rounded up to whole 64-byte lines (GE_PROBE_RW16=1: D = 200 -> 208 floats, every store covers whole lines and the row and
 # its accumulator row share no line) against D + 4 (the row ends mid-line).  Fresh process per run, alternating.
+# (GE_PROBE_RW16 existed in a probe build only; the result became the default row width, `--layout packed_records` is the old one:
+# tools/r02/records_ab.sh repeats the comparison with the shipped library.)
 mkdir -p gpurun_out/r02
 OUT=gpurun_out/r02/rw_probe.log
 : > $OUT
