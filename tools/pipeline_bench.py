@@ -15,12 +15,13 @@ ap.add_argument("--papers", type=int, default=90000)
 ap.add_argument("--dim", type=int, default=200)
 ap.add_argument("--epochs", type=int, default=8)
 ap.add_argument("--method", default="pglove")
+ap.add_argument("--layout", default="", help="comma list of device.layout flags (ablation)")
 a = ap.parse_args()
 g = synth.dblp_like_graph(a.authors, a.papers, 50)
 cfg = geglove.Configuration({"graph": "dblp-like", "method": a.method, "dim": a.dim, "threads": 1,
                              "bca": {"alpha": 0.1, "epsilon": 1e-3, "directed": True},
                              "opt": {"method": "adagrad", "tolerance": 1e-4, "maxiter": a.epochs}, "output": {"uri": []},
-                             "device": {"mode": "hogwild", "shuffle": "device", "seed": 42}})
+                             "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "layout": [x for x in a.layout.split(",") if x]}})
 t = time.perf_counter(); bca = geglove.BookmarkColoring(g, cfg); tb = time.perf_counter() - t
 n = bca.coOccurrenceCount()
 cnt = np.bincount(bca.J, minlength=g["V"])
