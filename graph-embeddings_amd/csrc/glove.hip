@@ -301,10 +301,12 @@ __global__ __launch_bounds__(64) void k_adagrad_exact(GloveParams p, int64_t k_b
 // in registers (bitonic network, no LDS, no barrier) and walks it sequentially:
 //   * a RUN of equal j keeps context[j], gradSqContext[j], cBias[j], gradSqCBias[j] in registers --
 //     loaded once, updated in place with exact sequential semantics inside the run, written once;
-//   * the focus side of every nonzero is gathered with 16-byte coalesced buffer loads (row base
-//     in SGPRs, hardware bounds check masks the lanes past D), the fp32 dot is wave-reduced, the
-//     fused AdaGrad update is written straight back; the next nonzero's focus rows are
-//     requested before the current one is computed.
+//   * the other side of every nonzero is streamed: 16-byte-per-lane buffer loads (row base in SGPRs,
+//     hardware bounds check masks the lanes past the row), the fp32 dot is wave-reduced, the fused
+//     AdaGrad update is written straight back.  The NEXT nonzero's streamed rows are requested into LDS
+//     (buffer_load ... lds) before the current one waits for its own, so a request has a whole step to
+//     complete (see s_setA / s_setB below for why LDS and not registers).
+// (Blocked layout, the default: the resident side is the hub COLUMN in hub chunks and the focus ROW elsewhere.)
 // Workers never lock (Hogwild).  ~10^4 workers are in flight where the JVM has <= #cores, so for
 // HOT columns (hub nodes that sit in a large share of the nonzeros) a plain read-modify-write
 // would lose most concurrent updates and training stalls (measured): their runs read
