@@ -283,9 +283,10 @@ def test_adam_amsgrad_deterministic_bit_exact(gpu, opt, method, D):
 
 @pytest.mark.parametrize("opt", ["adam", "amsgrad"])
 @pytest.mark.parametrize("hot", ["none", "auto"])
-def test_adam_amsgrad_hogwild_single_worker_replay(gpu, opt, hot, monkeypatch):
+@pytest.mark.parametrize("D", [52, 256, 300])      # fat rows in one register chunk; plain rows + bias vectors (lanes full); two chunks
+def test_adam_amsgrad_hogwild_single_worker_replay(gpu, opt, hot, D, monkeypatch):
     """Hogwild kernel with the moment update rules, one worker, blocked order: sequential replay by the oracle."""
-    V, N, D = 90, 2500, 52
+    V, N = 90, 2500
     I, J, X, xmax = synth.synthetic_coo(V, N, seed=17)
     cfg = make_config(D, "glove", opt=opt, mode="hogwild", shuffle="device", seed=5, hot=hot, workers=1, hot_theta=0.02)
     dev = geglove.createOptimizer(cfg, geglove.CooMatrix(V, I, J, X, xmax))
@@ -300,10 +301,19 @@ def test_adam_amsgrad_hogwild_single_worker_replay(gpu, opt, hot, monkeypatch):
         # AMSGrad's first epochs on this matrix are its unstable phase (mean cost 2 -> 14 -> 27): differences grow
         # from epoch to epoch there, so its second epoch gets ten times the room (measured: median 2e-4, 95 % 4e-3, max 0.3)
         room = 10.0 if (opt == "amsgrad" and it > 0) else 1.0
+        # Wider rows sum more products per dot (the device reduces across lanes, the oracle adds in order) and hold more elements whose
+        # second moment is still ~0, where a step is +-lr whatever the gradient's size: the same amplification, more of it.  The
+        # elementwise bounds are asserted in full at D = 52; at 256 / 300 the cost (above), the median and the 95th percentile are --
+        # identical figures with the library from before the LDS pipeline (tools/r02/kernel_ab.sh's `head`), so they are arithmetic, not ordering.
+        wide = D > 64
+        if wide:
+            room *= 20.0
+        if opt == "amsgrad" and D == 300:          # in its unstable phase from the first epoch on here (median 3e-3, single elements off by
+            continue                               # a factor 20, before and after the LDS pipeline alike): the job cost above is the check
         for name, got in dev.state().items():
             g, r = got.reshape(-1), np.asarray(ref[name]).reshape(-1)
             err = np.abs(g - r) / (np.abs(r) + 1e-3 * np.max(np.abs(r)))
-            assert np.median(err) <= 1e-4 * room and np.quantile(err, 0.95) < 5e-3 * room and np.max(err) < 0.1 * room, (name, it, float(np.max(err)))
+            assert np.median(err) <= 1e-4 * room and np.quantile(err, 0.95) < 5e-3 * room and (wide or np.max(err) < 0.1 * room), (name, it, float(np.max(err)))
 
 
 @pytest.mark.parametrize("opt", ["adam", "amsgrad"])
@@ -333,7 +343,7 @@ def _bf16_rne(a):
 
 
 @pytest.mark.parametrize("hot", ["none", "all"])
-@pytest.mark.parametrize("D", [52, 200, 300])
+@pytest.mark.parametrize("D", [52, 200, 256, 300])     # 256 fills its lanes: no fat accumulator rows, bias vectors of their own
 def test_bf16_embeddings_conflict_free_batch(gpu, D, hot):
     """bf16 rows + fp32 accumulators: one update per row, compared with the oracle applied to the SAME (bf16-valued)
     start state.  Accumulators and biases are fp32 and must agree to fp32 round-off; embedding rows are narrowed
@@ -389,6 +399,15 @@ def test_bf16_embeddings_state_roundtrip_and_extract(gpu):
     np.testing.assert_array_equal(got[exact], new.reshape(V, D)[exact])            # hub rows keep fp32
     np.testing.assert_array_equal(got[~exact], _bf16_rne(new).reshape(V, D)[~exact])
     np.testing.assert_allclose(opt.extractResultF32(), (opt.get_state("focus") + opt.get_state("context")) / 2, rtol=1e-6)
+    # the fp32 tables -- accumulator rows and the four scalars that ride behind them in the records -- keep what they are given,
+    # each without disturbing the others
+    sent = {}
+    for name in geglove.capi.STATE_NAMES[2:]:
+        sent[name] = rng.standard_normal(opt.get_state(name).size).astype(np.float32)
+        opt.set_state(name, sent[name])
+    for name, v in sent.items():
+        np.testing.assert_array_equal(opt.get_state(name), v, err_msg=name)
+    np.testing.assert_array_equal(opt.get_state("focus"), _bf16_rne(new))
     with pytest.raises(geglove.GeError):
         opt.device_ptr("context")
     with pytest.raises(geglove.GeError):           # the reference path is fp32: no deterministic bf16 mode
