@@ -384,6 +384,12 @@ __device__ __forceinline__ float4 widen_bf16x4(float2 raw) {
     return r;
 }
 #define GE_LDS(ptr) ((__attribute__((address_space(3))) void *)(ptr))
+// one load-to-LDS wave instruction: lane L brings W bytes from offset `voff` of the resource to lds + L * W
+template <int W> __device__ __forceinline__ void load_to_lds(__amdgpu_buffer_rsrc_t rs, float *lds, int voff) {
+    static_assert(W == 16 || W == 4, "16-byte or 4-byte lanes");
+    if constexpr (W == 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, GE_LDS(lds), 16, voff, 0, 0, 16 /* AUX_SC1 */);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, GE_LDS(lds), 4, voff, 0, 0, 16 /* AUX_SC1 */);
+}
 // s_waitcnt immediate (gfx9 layout) that waits until at most n vector-memory instructions are outstanding and for nothing else
 constexpr int wait_vmcnt(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 
@@ -458,14 +464,16 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
     // and is waited for only where the next step reads it (with loads into registers the compiler put the copies that merge
     // the two steps' values -- and with them the wait -- right behind the load, and every nonzero paid the full latency).
     // Two images per wave, one per array, so that the wait for one never covers the load into the other.
-    constexpr bool DMA = VW == 4;
-    constexpr int IMG = 256;                                                         // floats per 1 KB image: 64 lanes x 16 bytes
+    // Rows that are multiples of 16 bytes travel 16 bytes per lane; the others (VW < 4) 4 bytes per lane, VW instructions per register chunk.
+    constexpr int DMAW = VW == 4 ? 16 : 4;                                            // bytes per lane of one load-to-LDS
+    constexpr int N_Q = VW == 4 ? 1 : VW;                                              // such loads per register chunk
+    constexpr int IMG = 64 * VW;                                                       // floats per register chunk's image
     constexpr int IMG_R = EMB16 ? ((NCH + 1) / 2) * IMG : NCH * IMG;               // a bf16 row takes half the bytes
     constexpr int IMG_G = IMG_R, IMG_H = IMG_G + NCH * IMG;                          // offsets of the accumulator / second-moment images
     constexpr int IMG_B = IMG_H + (MOM ? NCH * IMG : 0);                             // three 256-byte slots for the bias scalars (not FAT)
     constexpr int SET_FLOATS = IMG_B + (FAT ? 0 : 3 * 64);
-    __shared__ float s_setA[DMA ? 4 * SET_FLOATS : 1], s_setB[DMA ? 4 * SET_FLOATS : 1];
-    float *const setA = s_setA + (DMA ? (threadIdx.x >> 6) * SET_FLOATS : 0), *const setB = s_setB + (DMA ? (threadIdx.x >> 6) * SET_FLOATS : 0);
+    __shared__ float s_setA[4 * SET_FLOATS], s_setB[4 * SET_FLOATS];
+    float *const setA = s_setA + (threadIdx.x >> 6) * SET_FLOATS, *const setB = s_setB + (threadIdx.x >> 6) * SET_FLOATS;
     double cost_acc = 0.0;
     bool inr[NCH];                          // lane holds real elements of a row (D % VW == 0)
 #pragma unroll
@@ -657,9 +665,6 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
 
         // decoded next nonzero + its prefetched rows
         int32_t n_oth = 0, n_key = KEY_PAD; float n_w = 0.0f; double n_l = 0.0;
-        // Register sets for the streamed rows where the rows cannot go through LDS (VW < 4: no 16-byte lanes).
-        struct Streamed { VT r[NCH], g[NCH], h[NCH]; float bb, gbb, hbb; };
-        Streamed sA{}, sB{};
         VT aN[NCH], gaN[NCH], haN[NCH]; float abN = 0.0f, gabN = 0.0f, habN = 0.0f;
         auto decode = [&](int pos) {
             const int q = pos >> 6, ln = pos & 63;
@@ -683,53 +688,24 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
             else rb = make_rsrc(B_rows + (int64_t)n_oth * DS, rbytes);
             const __amdgpu_buffer_rsrc_t rg = make_rsrc(B_gs + (int64_t)n_oth * DS, rbytes);
             const __amdgpu_buffer_rsrc_t rh = make_rsrc(B_m2 + (int64_t)n_oth * DS, MOM ? rbytes : 0u);
-            if constexpr (DMA) {
-                float *const img = decltype(SET)::value ? setB : setA;
+            float *const img = decltype(SET)::value ? setB : setA;
 #pragma unroll
-                for (int j = 0; j < IMG_R / IMG; ++j)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, GE_LDS(img + j * IMG), 16, (lane + j * 64) * 16, 0, 0, AUX_SC1);
+            for (int j = 0; j < (IMG_R / IMG) * N_Q; ++j)
+                load_to_lds<(VW == 4 ? 16 : 4)>(rb, img + j * (IMG / N_Q), (lane + j * 64) * DMAW);
 #pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, GE_LDS(img + IMG_G + q * IMG), 16, (lane + q * 64) * 16, 0, 0, AUX_SC1);
-                    if constexpr (MOM) __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, GE_LDS(img + IMG_H + q * IMG), 16, (lane + q * 64) * 16, 0, 0, AUX_SC1);
-                }
-                if constexpr (!FAT) {                  // lane 0 is the one lane inside these 4-byte resources
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(B_bias + n_oth, four), GE_LDS(img + IMG_B), 4, lane * 4, 0, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(B_gsb + n_oth, four), GE_LDS(img + IMG_B + 64), 4, lane * 4, 0, 0, AUX_SC1);
-                    if constexpr (MOM) __builtin_amdgcn_raw_ptr_buffer_load_lds(make_rsrc(B_m2b + n_oth, four), GE_LDS(img + IMG_B + 128), 4, lane * 4, 0, 0, AUX_SC1);
-                }
-                asm volatile("" ::: "memory");          // issued here, not where the scheduler would like them
-            } else {
-                Streamed &s = decltype(SET)::value ? sB : sA;
-#pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    s.r[q] = emb_load(rb, q);
-                    s.g[q] = buf_load<VW, AUX_SC1>(rg, (lane + q * 64) * VW * 4);
-                    if constexpr (MOM) s.h[q] = buf_load<VW, AUX_SC1>(rh, (lane + q * 64) * VW * 4);
-                }
-                if constexpr (!FAT) {
-                    s.bb  = buf_load_f32(make_rsrc(B_bias + n_oth, four), 0, true);
-                    s.gbb = buf_load_f32(make_rsrc(B_gsb + n_oth, four), 0, true);
-                    if constexpr (MOM) s.hbb = buf_load_f32(make_rsrc(B_m2b + n_oth, four), 0, true);
-                }
+            for (int j = 0; j < NCH * N_Q; ++j) {
+                load_to_lds<(VW == 4 ? 16 : 4)>(rg, img + IMG_G + j * (IMG / N_Q), (lane + j * 64) * DMAW);
+                if constexpr (MOM) load_to_lds<(VW == 4 ? 16 : 4)>(rh, img + IMG_H + j * (IMG / N_Q), (lane + j * 64) * DMAW);
             }
-        };
-        // waits until set SET has arrived (reads it), so that nothing of it is pending on the path that calls this
-        auto settle = [&](auto SET) {
-            if constexpr (DMA) { __builtin_amdgcn_s_waitcnt(wait_vmcnt(0)); asm volatile("" ::: "memory"); }
-            else {
-                Streamed &s = decltype(SET)::value ? sB : sA;
-#pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-#pragma unroll
-                    for (int t = 0; t < VW; ++t) {
-                        asm volatile("" : "+v"(comp<VW>(s.r[q], t)), "+v"(comp<VW>(s.g[q], t)));
-                        if constexpr (MOM) asm volatile("" : "+v"(comp<VW>(s.h[q], t)));
-                    }
-                }
-                if constexpr (!FAT) asm volatile("" : "+v"(s.bb), "+v"(s.gbb), "+v"(s.hbb));
+            if constexpr (!FAT) {                  // lane 0 is the one lane inside these 4-byte resources
+                load_to_lds<4>(make_rsrc(B_bias + n_oth, four), img + IMG_B, lane * 4);
+                load_to_lds<4>(make_rsrc(B_gsb + n_oth, four), img + IMG_B + 64, lane * 4);
+                if constexpr (MOM) load_to_lds<4>(make_rsrc(B_m2b + n_oth, four), img + IMG_B + 128, lane * 4);
             }
+            asm volatile("" ::: "memory");          // issued here, not where the scheduler would like them
         };
+        // waits until everything requested so far has arrived
+        auto settle = [&]() { __builtin_amdgcn_s_waitcnt(wait_vmcnt(0)); asm volatile("" ::: "memory"); };
         auto request_resident = [&]() {
             const int32_t id = n_key < 0 ? ~n_key : n_key;
             n_slot = id;
@@ -766,7 +742,7 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
             // the previous nonzero had the same streamed row: what was requested before its stores is stale.  Re-read behind
             // them (same wave, same address: in order) and wait right here, so that on the common path the set is known to be
             // older than those stores and the wait for it leaves them in flight.
-            if (again) { request_streamed(CUR, true); settle(CUR); again = false; }
+            if (again) { request_streamed(CUR, true); settle(); again = false; }
             if (open_new) {                       // the scalars of a new run; its rows follow below
                 cur_id = skey < 0 ? ~skey : skey;
                 // shared = other workers may hold this row too: hub columns (context side), pieces of a long focus row
@@ -805,35 +781,27 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
             // this nonzero's streamed rows
             VT bl[NCH], gbl[NCH], hbl[NCH];
             float bb = 0.0f, gbb = 0.0f, hbb = 0.0f;
-            if constexpr (DMA) {
-                // The wait is counted by hand (the compiler's own bookkeeping of loads into LDS loses them across the loop's
-                // back edge).  Memory instructions complete in order, and behind this set's request at least N_AFTER more
-                // have been issued on every path: the previous step's stores, one per table and register chunk (never
-                // skipped: lane 0 of every chunk holds row elements), or before the first step the resident rows' loads, one per
-                // table and chunk as well; then the request for the other set a few lines up.
-                constexpr int N_TAB = NCH * (2 + (MOM ? 1 : 0)) + (FAT ? 0 : 2 + (MOM ? 1 : 0));
-                constexpr int N_DMA = IMG_R / IMG + NCH * (1 + (MOM ? 1 : 0)) + (FAT ? 0 : 2 + (MOM ? 1 : 0));
-                constexpr int N_AFTER = N_TAB + N_DMA;
-                static_assert(N_AFTER < 64, "vmcnt is a 6-bit counter");
-                __builtin_amdgcn_s_waitcnt(wait_vmcnt(N_AFTER));       // the builtin, not asm text: the compiler's bookkeeping sees it
-                asm volatile("" ::: "memory");
-                const float *const img = decltype(CUR)::value ? setB : setA;
+            // The wait is counted by hand (the compiler's own bookkeeping of loads into LDS loses them across the loop's
+            // back edge).  Memory instructions complete in order, and behind this set's request at least N_AFTER more
+            // have been issued on every path: the previous step's stores, one per table and register chunk (never
+            // skipped: lane 0 of every chunk holds row elements), or before the first step the resident rows' loads, one per
+            // table and chunk as well; then the request for the other set a few lines up.
+            constexpr int N_TAB = NCH * (2 + (MOM ? 1 : 0)) + (FAT ? 0 : 2 + (MOM ? 1 : 0));
+            constexpr int N_DMA = ((IMG_R / IMG) + NCH * (1 + (MOM ? 1 : 0))) * N_Q + (FAT ? 0 : 2 + (MOM ? 1 : 0));
+            constexpr int N_AFTER = N_TAB + N_DMA;
+            static_assert(N_AFTER < 64, "vmcnt is a 6-bit counter");
+            __builtin_amdgcn_s_waitcnt(wait_vmcnt(N_AFTER));       // the builtin, not asm text: the compiler's bookkeeping sees it
+            asm volatile("" ::: "memory");
+            const float *const img = decltype(CUR)::value ? setB : setA;
 #pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    if constexpr (EMB16) bl[q] = widen_bf16x4(*reinterpret_cast<const float2 *>(img + (lane + q * 64) * 2));
-                    else bl[q] = *reinterpret_cast<const VT *>(img + (lane + q * 64) * 4);
-                    gbl[q] = *reinterpret_cast<const VT *>(img + IMG_G + (lane + q * 64) * 4);
-                    if constexpr (MOM) hbl[q] = *reinterpret_cast<const VT *>(img + IMG_H + (lane + q * 64) * 4);
-                }
-                if constexpr (!FAT) { bb = img[IMG_B]; gbb = img[IMG_B + 64]; if constexpr (MOM) hbb = img[IMG_B + 128]; }
-            } else {
-                const Streamed &cs = decltype(CUR)::value ? sB : sA;
-                bb = cs.bb; gbb = cs.gbb; hbb = cs.hbb;
+            for (int q = 0; q < NCH; ++q) {
+                if constexpr (EMB16) bl[q] = widen_bf16x4(*reinterpret_cast<const float2 *>(img + (lane + q * 64) * 2));
+                else bl[q] = *reinterpret_cast<const VT *>(img + (lane + q * 64) * VW);
+                gbl[q] = *reinterpret_cast<const VT *>(img + IMG_G + (lane + q * 64) * VW);
+                if constexpr (MOM) hbl[q] = *reinterpret_cast<const VT *>(img + IMG_H + (lane + q * 64) * VW);
             }
-            Streamed &cur = decltype(CUR)::value ? sB : sA;
-            auto &b  = [&]() -> VT (&)[NCH] { if constexpr (DMA) return bl;  else return cur.r; }();
-            auto &gb = [&]() -> VT (&)[NCH] { if constexpr (DMA) return gbl; else return cur.g; }();
-            auto &hb = [&]() -> VT (&)[NCH] { if constexpr (DMA) return hbl; else return cur.h; }();
+            if constexpr (!FAT) { bb = img[IMG_B]; gbb = img[IMG_B + 64]; if constexpr (MOM) hbb = img[IMG_B + 128]; }
+            VT (&b)[NCH] = bl, (&gb)[NCH] = gbl, (&hb)[NCH] = hbl;
             if constexpr (FAT) {
 #pragma unroll
                 for (int q = 0; q < NCH; ++q)
