@@ -47,7 +47,7 @@ def kernel_stats(layout):
 
 summary = {}
 traffic_entries = []
-for layout in ("default", "separate_tables", "packed_records", "dim100"):
+for layout in ("default", "separate_tables", "packed_records", "dim100", "bf16d300"):
     if not os.path.exists(os.path.join(src, "bench_%s.json" % layout)):
         continue
     b = bench_line(os.path.join(src, "bench_%s.json" % layout))
@@ -82,12 +82,12 @@ for layout in ("default", "separate_tables", "packed_records", "dim100"):
             with open(os.path.join(out_dir, "r02_bench_pmc_rows.csv"), "w", newline="") as f:
                 w = csv.DictWriter(f, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
         json.dump(s, open(os.path.join(out_dir, "r02_bench_pmc_summary.json"), "w"), indent=1)
-    if layout == "dim100":
-        json.dump(s, open(os.path.join(out_dir, "r02_dim100_pmc_summary.json"), "w"), indent=1)
+    if layout in ("dim100", "bf16d300"):
+        json.dump(s, open(os.path.join(out_dir, "r02_%s_pmc_summary.json" % layout), "w"), indent=1)
         ks = kernel_stats(layout)
         if ks:
-            shutil.copy(ks, os.path.join(out_dir, "r02_dim100_kernel_stats.csv"))
-    if layout in ("default", "dim100") and "derived" in s and "traffic_bytes_per_launch" in s["derived"]:
+            shutil.copy(ks, os.path.join(out_dir, "r02_%s_kernel_stats.csv" % layout))
+    if layout in ("default", "dim100", "bf16d300") and "derived" in s and "traffic_bytes_per_launch" in s["derived"]:
         c = b["config"]
         traffic_entries.append({"kernel": b["roofline"]["kernel"], "vocab": c["vocab"], "nnz_per_gpu": c["nnz_per_gpu"], "dim": c["dim"], "cost": c["cost"],
                                 "layout": "", "schedule_bytes": b["roofline"]["schedule_bytes_per_launch"], "row_stride": b["trainer"]["row_stride"],
@@ -96,7 +96,7 @@ for layout in ("default", "separate_tables", "packed_records", "dim100"):
                                           % ("bench" if layout == "default" else layout)})
 if traffic_entries:
     json.dump(traffic_entries, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
-json.dump({k: v for k, v in summary.items() if k != "dim100"}, open(os.path.join(out_dir, "r02_layout_evidence.json"), "w"), indent=1)
+json.dump({k: v for k, v in summary.items() if k not in ("dim100", "bf16d300")}, open(os.path.join(out_dir, "r02_layout_evidence.json"), "w"), indent=1)
 for layout, s in summary.items():
     d = s.get("derived", {})
     print(layout, "kernel_ms", round(s["roofline"]["kernel_ms"], 2), "frac", round(s["roofline"]["frac"], 3), {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()}, s["kernel_ms_by_pass"])
