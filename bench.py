@@ -266,6 +266,8 @@ def main():
                                             "updates_per_s_over_read_roofline_rate": (n_local / avg_kernel_s) / (8e12 / read_b)}},
             "mean_cost_first_last": [costs[0] / n_local, costs[-1] / n_local],
             "trainer": opt.info(),
+            # where the driver put the two record tables (which of its two modes a process runs in is fixed when they are placed)
+            "table_ptrs": {k: "0x%x" % opt.device_ptr(k)[0] for k in (("focus", "context") if args.dtype == "f32" else ("gsq_focus", "gsq_context"))},
             "gen_seconds": t_gen, "create_seconds": t_create,
         }
         if world == 1 and not args.no_cpu_baseline:
