@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--reserve-waves", type=int, default=256,
                     help="N>1 with --exchange overlap: wavefront slots the epoch kernel leaves free for the all-reduce kernels")
     ap.add_argument("--workers", type=int, default=0, help="sequential workers (wavefronts); 0 = fill the device (cfg.workers)")
-    ap.add_argument("--layout", default="", help="comma list of ge_glove_cfg.layout_flags: fixed_cuts, plain_long_rows, separate_tables, packed_records (default: none)")
+    ap.add_argument("--layout", default="", help="comma list of ge_glove_cfg.layout_flags: fixed_cuts, plain_long_rows, separate_tables, packed_records, first_placement (default: none)")
     ap.add_argument("--accum-sync-every", type=int, default=4, help="every how many context syncs the AdaGrad accumulators are reconciled too (N>1)")
     return ap.parse_args()
 

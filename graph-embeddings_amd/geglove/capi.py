@@ -18,7 +18,7 @@ GE_MODE_HOGWILD, GE_MODE_DETERMINISTIC = 0, 1
 GE_SHUFFLE_JAVA, GE_SHUFFLE_DEVICE, GE_SHUFFLE_NONE = 0, 1, 2
 GE_HOT_AUTO, GE_HOT_NONE, GE_HOT_ALL = 0, 1, 2
 GE_DTYPE_F32, GE_DTYPE_BF16 = 0, 1
-GE_LAYOUT_FIXED_CUTS, GE_LAYOUT_PLAIN_LONG_ROWS, GE_LAYOUT_SEPARATE_TABLES, GE_LAYOUT_PACKED_RECORDS = 1, 2, 4, 8
+GE_LAYOUT_FIXED_CUTS, GE_LAYOUT_PLAIN_LONG_ROWS, GE_LAYOUT_SEPARATE_TABLES, GE_LAYOUT_PACKED_RECORDS, GE_LAYOUT_FIRST_PLACEMENT = 1, 2, 4, 8, 16
 (GE_STATE_FOCUS, GE_STATE_CONTEXT, GE_STATE_FBIAS, GE_STATE_CBIAS, GE_STATE_GSQ_FOCUS,
  GE_STATE_GSQ_CONTEXT, GE_STATE_GSQ_FBIAS, GE_STATE_GSQ_CBIAS, GE_STATE_M2_FOCUS, GE_STATE_M2_CONTEXT,
  GE_STATE_M2_FBIAS, GE_STATE_M2_CBIAS) = range(12)
@@ -54,7 +54,8 @@ class GloveInfo(C.Structure):
                 ("blocks", C.c_int32), ("groups_in_flight", C.c_int32), ("hot_columns", C.c_int32),
                 ("hot_nonzeros", C.c_int64), ("hot_threshold", C.c_int64), ("chunks", C.c_int64), ("hub_chunks", C.c_int64),
                 ("long_rows", C.c_int64), ("shared_chunks", C.c_int64), ("flush_min", C.c_int32), ("row_stride", C.c_int32),
-                ("runs", C.c_int64), ("schedule_bytes", C.c_int64)]
+                ("runs", C.c_int64), ("schedule_bytes", C.c_int64), ("placements", C.c_int32), ("placement_best_ms", C.c_float),
+                ("placement_worst_ms", C.c_float), ("reserved_", C.c_int32)]
 
 
 class Csr(C.Structure):

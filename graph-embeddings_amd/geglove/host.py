@@ -42,7 +42,7 @@ class Configuration:
       mode: hogwild|deterministic   shuffle: java|device|none   seed: <long>   id: <ordinal>
       hot: auto|none|all   workers: <int>   dtype: f32|bf16
       hot_theta, stale_budget, flush_every, blocks_per_cu (ge_glove_cfg; 0 / absent = library default)
-      layout: [fixed_cuts, plain_long_rows, separate_tables, packed_records]   bca_table_slots, bca_pool_entries (ge_bca_cfg sizing)
+      layout: [fixed_cuts, plain_long_rows, separate_tables, packed_records, first_placement]   bca_table_slots, bca_pool_entries (ge_bca_cfg sizing)
     """
 
     def __init__(self, d=None):
@@ -197,7 +197,8 @@ _MODES = {"hogwild": capi.GE_MODE_HOGWILD, "deterministic": capi.GE_MODE_DETERMI
 _HOT = {"auto": capi.GE_HOT_AUTO, "none": capi.GE_HOT_NONE, "all": capi.GE_HOT_ALL}
 _SHUFFLES = {"java": capi.GE_SHUFFLE_JAVA, "device": capi.GE_SHUFFLE_DEVICE, "none": capi.GE_SHUFFLE_NONE}
 _LAYOUT = {"default": 0, "fixed_cuts": capi.GE_LAYOUT_FIXED_CUTS, "plain_long_rows": capi.GE_LAYOUT_PLAIN_LONG_ROWS,
-           "separate_tables": capi.GE_LAYOUT_SEPARATE_TABLES, "packed_records": capi.GE_LAYOUT_PACKED_RECORDS}
+           "separate_tables": capi.GE_LAYOUT_SEPARATE_TABLES, "packed_records": capi.GE_LAYOUT_PACKED_RECORDS,
+           "first_placement": capi.GE_LAYOUT_FIRST_PLACEMENT}
 
 
 class Adagrad:

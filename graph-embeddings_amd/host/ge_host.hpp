@@ -361,6 +361,7 @@ struct Configuration {
                             else if (nm == "plain_long_rows") c.device.layout_flags |= GE_LAYOUT_PLAIN_LONG_ROWS;
                             else if (nm == "separate_tables") c.device.layout_flags |= GE_LAYOUT_SEPARATE_TABLES;
                             else if (nm == "packed_records") c.device.layout_flags |= GE_LAYOUT_PACKED_RECORDS;
+                            else if (nm == "first_placement") c.device.layout_flags |= GE_LAYOUT_FIRST_PLACEMENT;
                             else if (!nm.empty() && nm != "default") throw std::invalid_argument("device.layout: unknown flag " + nm);
                         }
                     }

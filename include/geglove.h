@@ -154,8 +154,12 @@ typedef struct {
  * PACKED_RECORDS  fat rows exactly dim + 4 floats wide and records back to back, as before the alignment work.  Default:
  *                records start on 64-byte boundaries, and an fp32 row with dim % 4 == 0 is as wide as the whole 64-byte lines
  *                that hold dim + 1 floats (dim 200: 208; skipped where that would add more than 10 %), so every row store writes
- *                whole lines and a row shares no line with its accumulator row -- ablation / tests. */
-enum { GE_LAYOUT_FIXED_CUTS = 1, GE_LAYOUT_PLAIN_LONG_ROWS = 2, GE_LAYOUT_SEPARATE_TABLES = 4, GE_LAYOUT_PACKED_RECORDS = 8 };
+ *                whole lines and a row shares no line with its accumulator row -- ablation / tests.
+ * FIRST_PLACEMENT  take the record tables where the first allocation puts them.  Default: each side's table is allocated up to six
+ *                times (the earlier ones held meanwhile), a millisecond of random record reads and write-backs is timed on each, the
+ *                fastest is kept and the others freed -- where the driver places a table decides which of two epoch times a handle
+ *                gets (same process, same virtual address, 48 or 54 ms) -- ablation / tests. */
+enum { GE_LAYOUT_FIXED_CUTS = 1, GE_LAYOUT_PLAIN_LONG_ROWS = 2, GE_LAYOUT_SEPARATE_TABLES = 4, GE_LAYOUT_PACKED_RECORDS = 8, GE_LAYOUT_FIRST_PLACEMENT = 16 };
 
 /* What the library decided for a handle (reporting / DESIGN.md numbers). */
 typedef struct {
@@ -177,6 +181,9 @@ typedef struct {
     int64_t schedule_bytes;   /* bytes one epoch of this schedule has to move (what bench.py's roofline.achieved divides by the
                                  kernel time): per nonzero 20 B of (bA, bB, L, W) + the streamed row and its accumulator row(s)
                                  loaded and stored; per run the resident row and its accumulator row(s) loaded and published */
+    int32_t placements;       /* allocations tried for the record tables, both sides together (2 = no choice was made)              */
+    float   placement_best_ms, placement_worst_ms;   /* probe times of the kept and of the slowest candidate, summed over the two sides */
+    int32_t reserved_;
 } ge_glove_info;
 
 
