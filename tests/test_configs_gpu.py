@@ -122,3 +122,29 @@ def test_no_focus_row_is_resident_in_two_workers(gpu, per_row, dtype):
     assert (info["long_rows"] == rows) == (per_row > 128)
     np.testing.assert_allclose(gp, g1, rtol=1e-4)                       # no update's increment was discarded
     assert ((go / g1) < 0.9).sum() > 20                                 # the round-1 layout does lose runs here
+
+
+def test_record_tables_are_placed_by_probing_and_the_choice_changes_no_result(gpu):
+    """ge_glove_create allocates a large record table several times and keeps the candidate whose probe -- records read and written
+    back unchanged at random rows -- runs fastest.  The search is reported, `layout: first_placement` turns it off, and
+    the handle that went through it holds exactly the state of the one that did not (the probe touches the tables before they are
+    initialised and writes back what it read): one worker, same seed, bit for bit after an epoch."""
+    V, D = 60000, 200                                           # 60 000 records of 1 664 bytes: 100 MB per side, above the 64 MB floor
+    I, J, X, xmax = synth.synthetic_coo(V, 400000, seed=23)
+
+    def run(layout):
+        cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, workers=1, layout=layout)
+        opt = geglove.createOptimizer(cfg, geglove.CooMatrix(V, I, J, X, xmax))
+        info = opt.info()
+        cost = opt.epoch(0)
+        state = opt.state()
+        opt.close()
+        return info, cost, state
+
+    i0, c0, s0 = run(["first_placement"])
+    i1, c1, s1 = run([])
+    assert i0["placements"] == 2 and i0["placement_best_ms"] == 0.0
+    assert 4 <= i1["placements"] <= 12 and 0.0 < i1["placement_best_ms"] <= i1["placement_worst_ms"]
+    assert c0 == c1
+    for name in s0:
+        np.testing.assert_array_equal(s0[name].view(np.uint32), s1[name].view(np.uint32), err_msg=name)
