@@ -1209,7 +1209,9 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
                 // does to it is timed on each (0.91 - 0.97 ms on the good placements, 1.04 - 1.11 ms on the others), the fastest is kept.
                 float *blk = nullptr;
                 const size_t bytes = nr * (size_t)h->ds * sizeof(float);
-                const int tries = ((cfg->layout_flags & GE_LAYOUT_FIRST_PLACEMENT) || bytes < ((size_t)64 << 20)) ? 1 : 6;
+                // (candidates of one table together stay under 24 GB: allocating and freeing an 8 GB table costs a quarter of a second)
+                const int tries = ((cfg->layout_flags & GE_LAYOUT_FIRST_PLACEMENT) || bytes < ((size_t)64 << 20)) ? 1
+                                : (int)std::max<size_t>(2, std::min<size_t>(6, ((size_t)24 << 30) / bytes));
                 float *cand[6] = {}; float cand_ms[6] = {};
                 int n_cand = 0, best = 0;
                 for (int t = 0; t < tries; ++t) {

@@ -88,37 +88,51 @@ __global__ __launch_bounds__(256) void k_sync_turn_rows4(float *__restrict__ tab
                                                          float *__restrict__ base, void *__restrict__ wire_, void *__restrict__ own_) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-    for (int64_t r = wave; r < rows; r += n_waves) {
-        float4 *trow = reinterpret_cast<float4 *>(table + r * t_stride);
-        const int64_t d0 = r * cols4;                                       // index of the row's first group in the dense buffers
+    constexpr int U = 2;                                                    // rows in flight per wavefront: every load of both before any store
+    for (int64_t r0 = wave; r0 < rows; r0 += U * n_waves) {
         for (int32_t g = lane; g < cols4; g += 64) {
-            const float4 tv = trow[g];
-            float4 cv = reinterpret_cast<const float4 *>(base)[d0 + g];
-            float res[4] = {tv.x - cv.x, tv.y - cv.y, tv.z - cv.z, tv.w - cv.w};
-            if (LAND) {
-                float w[4], o[4];
-                if (W16) {
-                    const uint2 wv = reinterpret_cast<const uint2 *>(wire_)[d0 + g], ov = reinterpret_cast<const uint2 *>(own_)[d0 + g];
-                    w[0] = bf16_to_f32(wv.x & 0xffffu); w[1] = bf16_to_f32(wv.x >> 16); w[2] = bf16_to_f32(wv.y & 0xffffu); w[3] = bf16_to_f32(wv.y >> 16);
-                    o[0] = bf16_to_f32(ov.x & 0xffffu); o[1] = bf16_to_f32(ov.x >> 16); o[2] = bf16_to_f32(ov.y & 0xffffu); o[3] = bf16_to_f32(ov.y >> 16);
-                } else {
-                    const float4 wv = reinterpret_cast<const float4 *>(wire_)[d0 + g], ov = reinterpret_cast<const float4 *>(own_)[d0 + g];
-                    w[0] = wv.x; w[1] = wv.y; w[2] = wv.z; w[3] = wv.w; o[0] = ov.x; o[1] = ov.y; o[2] = ov.z; o[3] = ov.w;
-                }
-                float c[4] = {cv.x + w[0], cv.y + w[1], cv.z + w[2], cv.w + w[3]};
+            float4 tv[U], cv[U], wf[U], of[U]; uint2 wh[U], oh[U]; bool live[U];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) res[k] -= o[k];
-                trow[g] = make_float4(c[0] + res[0], c[1] + res[1], c[2] + res[2], c[3] + res[3]);
-                reinterpret_cast<float4 *>(base)[d0 + g] = make_float4(c[0], c[1], c[2], c[3]);
+            for (int u = 0; u < U; ++u) {
+                const int64_t r = r0 + u * n_waves;
+                live[u] = r < rows;
+                if (!live[u]) continue;
+                const int64_t d = r * cols4 + g;                            // index of the group in the dense buffers
+                tv[u] = reinterpret_cast<const float4 *>(table + r * t_stride)[g];
+                cv[u] = reinterpret_cast<const float4 *>(base)[d];
+                if (LAND) {
+                    if (W16) { wh[u] = reinterpret_cast<const uint2 *>(wire_)[d]; oh[u] = reinterpret_cast<const uint2 *>(own_)[d]; }
+                    else { wf[u] = reinterpret_cast<const float4 *>(wire_)[d]; of[u] = reinterpret_cast<const float4 *>(own_)[d]; }
+                }
             }
-            if (TAKE) {
-                if (W16) {
-                    const uint32_t h0 = f32_to_bf16_rne(res[0]), h1 = f32_to_bf16_rne(res[1]), h2 = f32_to_bf16_rne(res[2]), h3 = f32_to_bf16_rne(res[3]);
-                    const uint2 hv = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-                    reinterpret_cast<uint2 *>(wire_)[d0 + g] = hv; reinterpret_cast<uint2 *>(own_)[d0 + g] = hv;
-                } else {
-                    const float4 rv = make_float4(res[0], res[1], res[2], res[3]);
-                    reinterpret_cast<float4 *>(wire_)[d0 + g] = rv; reinterpret_cast<float4 *>(own_)[d0 + g] = rv;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!live[u]) continue;
+                const int64_t r = r0 + u * n_waves, d = r * cols4 + g;
+                float res[4] = {tv[u].x - cv[u].x, tv[u].y - cv[u].y, tv[u].z - cv[u].z, tv[u].w - cv[u].w};
+                if (LAND) {
+                    float w[4], o[4];
+                    if (W16) {
+                        w[0] = bf16_to_f32(wh[u].x & 0xffffu); w[1] = bf16_to_f32(wh[u].x >> 16); w[2] = bf16_to_f32(wh[u].y & 0xffffu); w[3] = bf16_to_f32(wh[u].y >> 16);
+                        o[0] = bf16_to_f32(oh[u].x & 0xffffu); o[1] = bf16_to_f32(oh[u].x >> 16); o[2] = bf16_to_f32(oh[u].y & 0xffffu); o[3] = bf16_to_f32(oh[u].y >> 16);
+                    } else {
+                        w[0] = wf[u].x; w[1] = wf[u].y; w[2] = wf[u].z; w[3] = wf[u].w; o[0] = of[u].x; o[1] = of[u].y; o[2] = of[u].z; o[3] = of[u].w;
+                    }
+                    const float c[4] = {cv[u].x + w[0], cv[u].y + w[1], cv[u].z + w[2], cv[u].w + w[3]};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) res[k] -= o[k];
+                    reinterpret_cast<float4 *>(table + r * t_stride)[g] = make_float4(c[0] + res[0], c[1] + res[1], c[2] + res[2], c[3] + res[3]);
+                    reinterpret_cast<float4 *>(base)[d] = make_float4(c[0], c[1], c[2], c[3]);
+                }
+                if (TAKE) {
+                    if (W16) {
+                        const uint32_t h0 = f32_to_bf16_rne(res[0]), h1 = f32_to_bf16_rne(res[1]), h2 = f32_to_bf16_rne(res[2]), h3 = f32_to_bf16_rne(res[3]);
+                        const uint2 hv = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+                        reinterpret_cast<uint2 *>(wire_)[d] = hv; reinterpret_cast<uint2 *>(own_)[d] = hv;
+                    } else {
+                        const float4 rv = make_float4(res[0], res[1], res[2], res[3]);
+                        reinterpret_cast<float4 *>(wire_)[d] = rv; reinterpret_cast<float4 *>(own_)[d] = rv;
+                    }
                 }
             }
         }
