@@ -54,6 +54,7 @@ def parse():
                     help="N>1 with --exchange overlap: wavefront slots the epoch kernel leaves free for the all-reduce kernels")
     ap.add_argument("--workers", type=int, default=0, help="sequential workers (wavefronts); 0 = fill the device (cfg.workers)")
     ap.add_argument("--layout", default="", help="comma list of ge_glove_cfg.layout_flags: fixed_cuts, plain_long_rows, separate_tables, packed_records, first_placement (default: none)")
+    ap.add_argument("--no-other-form", action="store_true", help="N>1: do not time the other exchange form behind the quoted region")
     ap.add_argument("--accum-sync-every", type=int, default=4, help="every how many context syncs the AdaGrad accumulators are reconciled too (N>1)")
     return ap.parse_args()
 
@@ -107,13 +108,56 @@ def cpu_baseline(args, V, D, I, J, X, xmax):
                       % (m_t, cores, dt_t, m_1, dt_1)}
 
 
+def launch_ranks(n):
+    """`python3 bench.py --gpus N` from a plain shell: this process becomes the launcher.  It starts N copies of itself, one rank
+    per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT as torch.distributed.run would set them), waits
+    for them and exits with their status.  It never imports torch and never touches a GPU (nothing may exec or fork after a HIP
+    call on this pool), and it never prints a bench line itself: rank 0 does, or nobody does and the exit code is non-zero."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", GE_BENCH_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    status = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                print("bench.py: rank %d exited with status %d; stopping the other ranks" % (procs.index(p), rc), file=sys.stderr, flush=True)
+                for q in alive:                                     # exactly the processes started above, by handle
+                    q.terminate()
+                t_end = time.time() + 20
+                for q in alive:
+                    try:
+                        q.wait(timeout=max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+    raise SystemExit(status)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and os.environ.get("GE_BENCH_LAUNCHED") != "1":
+        launch_ranks(args.gpus)                                   # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: a bench line must carry the number of GPUs it ran on" % (args.gpus, world))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
@@ -127,6 +171,9 @@ def main():
         # (RCCL refuses two ranks per device); never used by the driver.
         if os.environ.get("GE_BENCH_ONE_DEVICE") == "1":
             local_rank = 0
+        if local_rank >= torch.cuda.device_count():             # counting devices does not initialise the GPU
+            raise SystemExit("bench.py --gpus %d: rank %d has no GPU (%d visible); no line is printed for a run that cannot have %d GPUs"
+                             % (world, rank, torch.cuda.device_count(), world))
         torch.cuda.set_device(local_rank)
         backend = os.environ.get("GE_BENCH_BACKEND", "nccl")
         if backend == "nccl":
@@ -162,10 +209,10 @@ def main():
     if world > 1:
         sync = parallel.context_sync_for(opt, torch.device("cuda", local_rank), lazy_every=args.accum_sync_every, wire=args.wire)
 
-    def step(it):
+    def step(it, form=None):
         c = opt.epoch(it)
         if sync is not None and (it + 1) % args.sync_every == 0:
-            if args.exchange == "overlap":
+            if (form or args.exchange) == "overlap":
                 sync.turn()                         # lands the deltas sent one exchange ago and sends this step's: the all-reduce runs under the next epoch
             else:
                 sync.sync()
@@ -192,6 +239,22 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
+    # N > 1: the OTHER exchange form on the same handles, timed the same way right behind the quoted region (the quoted `value`
+    # is the form --exchange names; a scaling record then holds both: the overlapped form is faster, the synchronous one
+    # trains the better model per epoch).  The handle keeps its worker count (reserved slots) in both.
+    other = None
+    if sync is not None and not args.no_other_form:
+        form2 = "sync" if args.exchange == "overlap" else "overlap"
+        costs2, k_ms2, nl2 = [], 0.0, 0
+        step(args.warmup + args.steps, form2); fence()          # one untimed step to change over
+        t2 = time.perf_counter()
+        for k in range(args.steps):
+            costs2.append(step(args.warmup + args.steps + 1 + k, form2))
+            ms, nl = opt.last_kernel_ms()
+            k_ms2 += ms; nl2 += nl
+        fence()
+        other = {"exchange": form2, "dt": time.perf_counter() - t2, "costs": costs2, "kernel_ms": k_ms2 / max(nl2, 1)}
+
     # what THIS box's memory system gives a plain device-to-device copy (1 GiB, read + written bytes), right after the timed
     # region: boxes of the pool differ by 10-15 % in the epoch time of one binary, and this says which kind ran
     box_copy = None
@@ -202,13 +265,22 @@ def main():
             box_copy = g.value
 
     total_updates = n_local * args.steps
+    n_global = n_local
+    kernel_ms_max = kernel_ms / max(launches, 1)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, kernel_ms_max, other["dt"] if other else 0.0, other["kernel_ms"] if other else 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        u = torch.tensor([float(total_updates)], dtype=torch.float64, device="cuda")
+        dt, kernel_ms_max = float(t[0].item()), float(t[1].item())
+        if other:
+            other["dt"], other["kernel_ms"] = float(t[2].item()), float(t[3].item())
+        # the cost the ranks must agree on (Optimizer.java:96-97: the sum of the jobs' costs over the number of nonzeros), per step
+        u = torch.tensor([float(total_updates), float(n_local)] + [float(c) for c in costs] + ([float(c) for c in other["costs"]] if other else []),
+                         dtype=torch.float64, device="cuda")
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        total_updates = float(u.item())
+        total_updates, n_global = float(u[0].item()), float(u[1].item())
+        costs = [float(x) for x in u[2:2 + len(costs)].tolist()]
+        if other:
+            other["costs"] = [float(x) for x in u[2 + len(costs):].tolist()]
 
     if rank == 0:
         info = opt.info()
@@ -264,12 +336,22 @@ def main():
                                             "bytes_per_launch": n_local * (read_b + write_b),
                                             "equivalent_GBps": n_local * (read_b + write_b) / avg_kernel_s / 1e9,
                                             "updates_per_s_over_read_roofline_rate": (n_local / avg_kernel_s) / (8e12 / read_b)}},
-            "mean_cost_first_last": [costs[0] / n_local, costs[-1] / n_local],
+            "mean_cost_first_last": [costs[0] / n_global, costs[-1] / n_global],
+            # N > 1: every rank's job costs summed over all nonzeros of the job, per step (warm-up steps first)
+            "mean_cost_per_step": [c / n_global for c in costs],
             "trainer": opt.info(),
             # where the driver put the two record tables (which of its two modes a process runs in is fixed when they are placed)
             "table_ptrs": {k: "0x%x" % opt.device_ptr(k)[0] for k in (("focus", "context") if args.dtype == "f32" else ("gsq_focus", "gsq_context"))},
             "gen_seconds": t_gen, "create_seconds": t_create,
         }
+        if world > 1:
+            out["exchange"] = {"form": args.exchange, "kernel_ms_max_over_ranks": kernel_ms_max,
+                               "ms_per_step_minus_kernel_ms": dt / args.steps * 1e3 - kernel_ms_max}
+            if other:
+                out["exchange"]["other_form"] = {"form": other["exchange"], "value": total_updates / other["dt"], "ms_per_step": other["dt"] / args.steps * 1e3,
+                                                 "kernel_ms_max_over_ranks": other["kernel_ms"],
+                                                 "mean_cost_per_step": [c / n_global for c in other["costs"]],
+                                                 "note": "the %d steps right behind the quoted region, same handles" % args.steps}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, V, D, I, J, X, xmax)
         print(json.dumps(out), flush=True)

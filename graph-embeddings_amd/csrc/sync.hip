@@ -209,13 +209,18 @@ unsigned grid_for(int64_t n, int cus) { return (unsigned)std::max<int64_t>(1, st
 struct ge_local_group {
     int world = 0;
     std::mutex m; std::condition_variable cv; int arrived = 0; unsigned long generation = 0;
+    bool aborted = false;                                  // a rank failed: nobody may wait for it any more
     std::vector<std::vector<unsigned char>> stage;        // one host buffer per rank
-    void barrier() {
+    // false: the group was aborted (before or while waiting); the caller returns GE_ERR_STATE
+    bool barrier() {
         std::unique_lock<std::mutex> lk(m);
+        if (aborted) return false;
         const unsigned long g = generation;
         if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != g; });
+        else cv.wait(lk, [&] { return generation != g || aborted; });
+        return !aborted;
     }
+    void abort() { std::lock_guard<std::mutex> lk(m); aborted = true; cv.notify_all(); }
 };
 
 struct ge_sync {
@@ -245,11 +250,15 @@ namespace {
 // sum of every rank's device buffer, in rank order, back into each rank's buffer (blocking; the caller's stream is idle)
 ge_status local_allreduce(ge_local_group *g, int rank, void *buf, int64_t count, int32_t dtype, bool bcast, int src) {
     const size_t bytes = (size_t)count * (dtype == GE_DTYPE_BF16 ? 2 : dtype == 2 ? 8 : 4);       // dtype 2: host doubles (scalars)
+    // a rank whose copy fails still reaches the barriers (its peers would wait for ever otherwise) and aborts the group
+    static const char *gone = "ge_local_group: another rank of the group failed";
     std::vector<unsigned char> &mine = g->stage[(size_t)rank];
     mine.resize(bytes);
+    hipError_t he = hipSuccess;
     if (dtype == 2) std::memcpy(mine.data(), buf, bytes);
-    else GE_HIP(hipMemcpy(mine.data(), buf, bytes, hipMemcpyDeviceToHost));
-    g->barrier();
+    else he = hipMemcpy(mine.data(), buf, bytes, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) { g->abort(); return ge::fail(GE_ERR_HIP, "local all-reduce: copy to the host failed: %s", hipGetErrorString(he)); }
+    if (!g->barrier()) return ge::fail(GE_ERR_STATE, "%s", gone);
     std::vector<unsigned char> out(bytes);
     if (bcast) std::memcpy(out.data(), g->stage[(size_t)src].data(), bytes);
     else if (dtype == GE_DTYPE_F32) {
@@ -271,9 +280,12 @@ ge_status local_allreduce(ge_local_group *g, int rank, void *buf, int64_t count,
             o[k] = a;
         }
     }
-    g->barrier();                                                        // every rank has read the stage
+    if (!g->barrier()) return ge::fail(GE_ERR_STATE, "%s", gone);      // every rank has read the stage
     if (dtype == 2) std::memcpy(buf, out.data(), bytes);
-    else GE_HIP(hipMemcpy(buf, out.data(), bytes, hipMemcpyHostToDevice));
+    else if ((he = hipMemcpy(buf, out.data(), bytes, hipMemcpyHostToDevice)) != hipSuccess) {
+        g->abort();
+        return ge::fail(GE_ERR_HIP, "local all-reduce: copy to the device failed: %s", hipGetErrorString(he));
+    }
     return GE_OK;
 }
 
@@ -387,6 +399,7 @@ ge_status ge_local_group_create(int32_t world, ge_local_group **out) {
     return GE_OK;
 }
 void ge_local_group_destroy(ge_local_group *g) { delete g; }
+void ge_local_group_abort(ge_local_group *g) { if (g) g->abort(); }
 
 ge_status ge_rccl_unique_id(void *id128) {
     if (!id128) return ge::fail(GE_ERR_ARG, "null id buffer");
@@ -513,9 +526,13 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
 }
 ge_status ge_sync_create(ge_glove *h, const ge_sync_cfg *cfg, ge_sync **out) { GE_GUARD(ge_sync_create_impl(h, cfg, out)); }
 
-ge_status ge_sync_begin(ge_sync *s, int32_t everything) { GE_GUARD(turn(s, false, true, everything != 0)); }
-ge_status ge_sync_finish(ge_sync *s) { GE_GUARD(turn(s, true, false, false)); }
-ge_status ge_sync_turn(ge_sync *s) { GE_GUARD(turn(s, true, true, false)); }
+// a rank of a local group that fails inside an exchange call takes the group down with it: its peers' barriers return
+// GE_ERR_STATE instead of waiting for a rank that will not come
+static ge_status with_abort(ge_sync *s, ge_status st) { if (st != GE_OK && s && s->loop) s->loop->abort(); return st; }
+static ge_status turn_guarded(ge_sync *s, bool land, bool take, bool everything) { GE_GUARD(turn(s, land, take, everything)); }
+ge_status ge_sync_begin(ge_sync *s, int32_t everything) { return with_abort(s, turn_guarded(s, false, true, everything != 0)); }
+ge_status ge_sync_finish(ge_sync *s) { return with_abort(s, turn_guarded(s, true, false, false)); }
+ge_status ge_sync_turn(ge_sync *s) { return with_abort(s, turn_guarded(s, true, true, false)); }
 ge_status ge_sync_sync(ge_sync *s) {          // lands what an earlier turn left in flight, takes, lands: nothing is in flight afterwards
     ge_status st = ge_sync_turn(s);
     return st == GE_OK ? ge_sync_finish(s) : st;
@@ -558,7 +575,8 @@ static ge_status ge_sync_replicate_impl(ge_sync *s, int32_t src) {
     }
     return GE_OK;
 }
-ge_status ge_sync_replicate(ge_sync *s, int32_t src) { GE_GUARD(ge_sync_replicate_impl(s, src)); }
+static ge_status replicate_guarded(ge_sync *s, int32_t src) { GE_GUARD(ge_sync_replicate_impl(s, src)); }
+ge_status ge_sync_replicate(ge_sync *s, int32_t src) { return with_abort(s, replicate_guarded(s, src)); }
 
 // Host scalars (the epoch's cost sums, a max over shards) over the same transport, so that a host without a
 // collective library of its own (the Java module) needs nothing else.  op: 0 = sum, 1 = max.  Blocking.
@@ -581,6 +599,7 @@ static ge_status ge_sync_allreduce_f64_impl(ge_sync *s, double *values, int32_t 
     if (he != hipSuccess) return ge::fail(GE_ERR_HIP, "scalar all-reduce: %s", hipGetErrorString(he));
     return GE_OK;
 }
-ge_status ge_sync_allreduce_f64(ge_sync *s, double *values, int32_t n, int32_t op) { GE_GUARD(ge_sync_allreduce_f64_impl(s, values, n, op)); }
+static ge_status allreduce_guarded(ge_sync *s, double *values, int32_t n, int32_t op) { GE_GUARD(ge_sync_allreduce_f64_impl(s, values, n, op)); }
+ge_status ge_sync_allreduce_f64(ge_sync *s, double *values, int32_t n, int32_t op) { return with_abort(s, allreduce_guarded(s, values, n, op)); }
 
 }  // extern "C"

@@ -32,7 +32,7 @@ SYMBOLS = (
     "ge_glove_extract_f64", "ge_glove_get_state", "ge_glove_set_state", "ge_glove_device_ptr",
     "ge_glove_epoch_order", "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
     "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn_bf16", "ge_glove_context_layout",
-    "ge_local_group_create", "ge_local_group_destroy", "ge_rccl_unique_id", "ge_rccl_selftest", "ge_sync_cfg_size", "ge_sync_create", "ge_sync_begin", "ge_sync_finish", "ge_sync_turn", "ge_sync_sync",
+    "ge_local_group_create", "ge_local_group_destroy", "ge_local_group_abort", "ge_rccl_unique_id", "ge_rccl_selftest", "ge_sync_cfg_size", "ge_sync_create", "ge_sync_begin", "ge_sync_finish", "ge_sync_turn", "ge_sync_sync",
     "ge_sync_replicate", "ge_sync_allreduce_f64", "ge_sync_destroy",
     "ge_sim_cfg_default", "ge_sim_cfg_size", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_copy_bandwidth", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_bca_cfg_size", "ge_device_count",
 )
@@ -166,6 +166,7 @@ def lib():
     L.ge_rccl_unique_id.argtypes = [vp]
     L.ge_local_group_create.argtypes = [C.c_int32, C.POINTER(vp)]
     L.ge_local_group_destroy.argtypes = [vp]; L.ge_local_group_destroy.restype = None
+    L.ge_local_group_abort.argtypes = [vp]; L.ge_local_group_abort.restype = None
     L.ge_rccl_selftest.argtypes = [C.c_int32]
     L.ge_sync_cfg_size.argtypes = []; L.ge_sync_cfg_size.restype = C.c_int32
     L.ge_sync_create.argtypes = [vp, C.POINTER(SyncCfg), C.POINTER(vp)]

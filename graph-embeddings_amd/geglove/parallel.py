@@ -98,11 +98,36 @@ class _TorchTransport:
             return capi.GE_ERR_STATE
 
 
+class LocalGroup:
+    """ge_local_group: the ranks are THREADS of this process (one ge_glove + one ContextSync each) and meet in host memory.
+    What the C++ CLI uses for `device: {gpus: N}` on fewer than N devices, and what lets one GPU run an N-rank exchange through
+    the library's own take / land kernels (the callback transport needs a process per rank; a box allows few of those)."""
+
+    def __init__(self, world):
+        self.world = int(world)
+        self._g = C.c_void_p()
+        capi.check(capi.lib().ge_local_group_create(self.world, C.byref(self._g)))
+
+    def abort(self):
+        capi.lib().ge_local_group_abort(self._g)
+
+    def close(self):
+        if getattr(self, "_g", None) and self._g.value:
+            capi.lib().ge_local_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ContextSync:
     """ge_sync of one rank's trainer handle.  sync() = exact replicas after every step; turn() = the all-reduce of step k
     runs under the epoch of step k + 1 (deltas land one step late); replicate() ends a run with identical fp32 tables."""
 
-    def __init__(self, optimizer, world, rank, wire="bf16", accum_every=4, transport="rccl", device=None, group=None, rccl_id=None):
+    def __init__(self, optimizer, world, rank, wire="bf16", accum_every=4, transport="rccl", device=None, group=None, rccl_id=None, local_group=None):
         self.world, self.rank = int(world), int(rank)
         self._h = C.c_void_p()
         self._keep = None
@@ -110,18 +135,27 @@ class ContextSync:
         cfg.world, cfg.rank = self.world, self.rank
         cfg.wire = capi.GE_DTYPE_BF16 if wire == "bf16" else capi.GE_DTYPE_F32
         cfg.accum_every = int(accum_every)
-        if self.world > 1 and transport == "torch":
+        if self.world > 1 and local_group is not None:
+            self._keep = local_group                      # the group outlives every ge_sync made for it
+            cfg.local_group = local_group._g
+        elif self.world > 1 and transport == "torch":
             self._keep = _TorchTransport(device, group)
             cfg.transport = C.pointer(self._keep.struct)
         elif self.world > 1:
             if rccl_id is None:
+                # rank 0 makes the id and EVERY rank takes part in the broadcast whatever happened on rank 0: a failure there
+                # (librccl not loadable) travels as an error marker, so that all ranks raise together and reach the caller's
+                # vote (context_sync_for) instead of one rank leaving the others inside the broadcast
                 import torch.distributed as dist
                 box = [None]
                 if dist.get_rank(group) == 0:
                     buf = (C.c_char * 128)()
-                    capi.check(capi.lib().ge_rccl_unique_id(buf))
-                    box[0] = bytes(buf.raw)
+                    st = capi.lib().ge_rccl_unique_id(buf)
+                    box[0] = bytes(buf.raw) if st == capi.GE_OK else (int(st), capi.lib().ge_last_error().decode(errors="replace"))
                 dist.broadcast_object_list(box, src=0, group=group)
+                if not isinstance(box[0], (bytes, bytearray)):
+                    st, msg = box[0] if box[0] else (capi.GE_ERR_STATE, "no RCCL id arrived from rank 0")
+                    raise capi.GeError(st, "rank 0 could not make an RCCL unique id: " + msg)
                 rccl_id = box[0]
             self._keep = C.create_string_buffer(bytes(rccl_id), 128)
             cfg.rccl_id = C.cast(self._keep, C.c_void_p)

@@ -1008,8 +1008,11 @@ public:
             cfg.hot_theta = (float)config_.device.hot_theta; cfg.stale_budget = (float)config_.device.stale_budget;
             cfg.flush_every = config_.device.flush_every; cfg.blocks_per_cu = config_.device.blocks_per_cu; cfg.layout_flags = config_.device.layout_flags;
             ge_glove *h = nullptr;
+            if (const char *f = std::getenv("GE_HOST_FAIL_RANK")) if (std::atoi(f) == r) throw std::runtime_error("GE_HOST_FAIL_RANK: this rank was told to fail (test hook)");
             check(ge_glove_create(&cfg, m_.dataI() + lo, m_.dataJ() + lo, m_.dataX() + lo, &h));
             std::unique_ptr<ge_glove, void (*)(ge_glove *)> hg(h, ge_glove_destroy);
+            bar.wait();                                         // every rank has its handle: only then the collective ge_sync_create (a rank
+                                                                // that failed above has abandoned the barrier, and everybody leaves here)
             ge_sync_cfg sc{};
             sc.world = world; sc.rank = r; sc.wire = config_.device.wire == "f32" ? GE_DTYPE_F32 : GE_DTYPE_BF16;
             sc.accum_every = config_.device.accum_every; sc.rccl_id = use_rccl ? id : nullptr; sc.local_group = grp;
@@ -1043,7 +1046,15 @@ public:
                 const size_t g = (size_t)rb * (size_t)D + k;
                 result_[g] = (double)((focus[k] + context0[g]) / 2.0f);
             }
-            } catch (...) { bar.abandon(); throw; }
+            } catch (const std::exception &e) {
+                // the peers may be waiting for this rank at the host barrier, in an exchange of the local group, or inside RCCL
+                bar.abandon();
+                if (grp) ge_local_group_abort(grp);
+                std::fprintf(stderr, "rank %d failed: %s\n", r, e.what());
+                std::fflush(stderr);
+                if (use_rccl) std::_Exit(1);                    // nothing releases a rank blocked in a collective of a communicator one
+                throw;                                          // member has left: end the process (Main.java:150-153)
+            }
         });
         opt.result = result_;
         opt.finalCost = finalCost;

@@ -417,6 +417,10 @@ typedef struct {
  * last ge_sync_destroy. */
 ge_status ge_local_group_create(int32_t world, ge_local_group **out);
 void ge_local_group_destroy(ge_local_group *g);
+/* A rank thread that fails OUTSIDE the ge_sync calls (its ge_glove_create, its epoch) calls this before it leaves: every peer
+ * waiting in -- or arriving at -- an exchange of the group returns GE_ERR_STATE instead of waiting for a rank that will not
+ * come.  (A rank that fails INSIDE a ge_sync call aborts its group itself.)  The group stays aborted. */
+void ge_local_group_abort(ge_local_group *g);
 
 ge_status ge_rccl_unique_id(void *id128);
 /* Opens RCCL, makes a one-rank communicator on `device`, runs a sum and a broadcast through it and checks the data: what a
@@ -438,7 +442,9 @@ ge_status ge_sync_sync(ge_sync *s);
 /* Ends a run: lands what is in flight, exchanges everything not sent yet, then every rank takes rank src's fp32 tables. */
 ge_status ge_sync_replicate(ge_sync *s, int32_t src);
 /* n host doubles summed (op 0) or maximised (op 1) over the ranks through RCCL: the epoch's cost (Optimizer.java:94-96 needs
- * the sum over all jobs), BookmarkColoring's max over shards.  Blocking. */
+ * the sum over all jobs), BookmarkColoring's max over shards.  Blocking, and ordered on the communicator BEHIND whatever
+ * ge_sync_turn has put on the wire: reduce an epoch's cost BEFORE that epoch's ge_sync_turn (epoch -> allreduce(cost) ->
+ * turn), or the host waits for the whole context all-reduce and the overlap with the next epoch is lost. */
 ge_status ge_sync_allreduce_f64(ge_sync *s, double *values, int32_t n, int32_t op);
 void ge_sync_destroy(ge_sync *s);
 

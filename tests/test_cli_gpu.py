@@ -267,3 +267,14 @@ def test_cli_two_ranks_in_one_process(gpu, tmp_path):
         rho = np.corrcoef((n1 @ n1.T)[iu], (n2 @ n2.T)[iu])[0, 1]
         print("cli gpus 2 %s: cost / one GPU %s, pairwise-cosine correlation %.4f" % (name, np.round(np.array(costs) / np.array(one), 3).tolist(), rho))
         assert rho > 0.9
+
+
+def test_cli_exits_nonzero_when_one_rank_fails(gpu, tmp_path):
+    """with `gpus: 2` a rank that fails (here: told to, before its ge_glove_create) must end the run with a non-zero
+    status like Main.java:150-153 does -- not leave the other rank waiting at the host barrier or inside the group's exchange."""
+    _write_synthetic_nt(tmp_path / "g.nt")
+    (tmp_path / "two.yml").write_text(_MULTI_YML % ("two.gecoo", "  gpus: 2\n  exchange: sync\n  wire: f32\n"))
+    env = dict(os.environ, GE_HOST_FAIL_RANK="1")
+    r = subprocess.run([EXE, "-c", "two.yml"], cwd=tmp_path, capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0
+    assert "GE_HOST_FAIL_RANK" in (r.stderr + r.stdout)

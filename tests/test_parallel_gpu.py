@@ -274,3 +274,114 @@ def test_exchange_turn_bf16_matches_a_numpy_model(gpu, land, take, pad):
         assert np.array_equal(back(d_t)[5 * D:6 * D], t16[5 * D:6 * D])   # nothing landed on row 5: its bf16 value is untouched by the rounding
 
 
+# ---- eight ranks on ONE GPU: rank threads of this process meeting in a ge_local_group (VERDICT r02 #1b) ------------------
+# Eight contributors through the library's own mean-over-contributors (cBias), summed rows / lazily summed accumulators and
+# the bf16 wire with error feedback -- what an 8-GPU node runs, minus RCCL (the group sums in host memory, in rank order).
+W8 = dict(world=8, V=100_000, N=3_000_000, D=200, epochs=7)
+_ORACLE8 = {}
+
+
+def _oracle8():
+    if not _ORACLE8:
+        import oracle as O
+        from geglove import synth
+        I, J, X, xmax = synth.synthetic_coo(W8["V"], W8["N"], seed=13)
+        ora = O.Glove(W8["V"], W8["D"], I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
+        _ORACLE8["ref"] = [ora.epoch() for _ in range(W8["epochs"])]
+        ora.close()
+    return _ORACLE8["ref"]
+
+
+def _run_rank_threads(world, V, N, D, epochs, exchange, wire, dtype="f32", lazy_every=2, fail_rank=None):
+    """One thread per rank; every rank owns a ge_glove handle (its block of focus rows) on device 0 and a ge_sync of the group."""
+    import threading
+    import geglove
+    from geglove import parallel, synth
+    from helpers import make_config
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
+    grp = parallel.LocalGroup(world)
+    bar = threading.Barrier(world)
+    cost = np.zeros((epochs, world))
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        opt = sync = None
+        try:
+            rows = parallel.shard_rows(V, world, r)
+            si, sj, sx = parallel.shard_nonzeros(I, J, X, rows)
+            cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, row_range=rows, dtype=dtype,
+                              workers=-256 if exchange == "overlap" else 0)
+            opt = geglove.Adagrad(geglove.CooMatrix(V, si, sj, sx, xmax), cfg, cfg.costFunction())
+            bar.wait(timeout=600)
+            sync = parallel.ContextSync(opt, world, r, wire=wire, accum_every=lazy_every, local_group=grp)
+            for it in range(epochs):
+                if fail_rank == r and it == 1:
+                    raise RuntimeError("rank %d leaves" % r)
+                cost[it, r] = opt.epoch(it)
+                sync.turn() if exchange == "overlap" else sync.sync()
+            sync.replicate()
+            out[r] = {k: opt.get_state(k) for k in CTX}
+        except Exception as e:              # noqa: BLE001 -- reported by the caller
+            err[r] = e
+            grp.abort()
+            bar.abort()
+        finally:
+            if sync is not None: sync.close()
+            if opt is not None: opt.close()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=1500)
+    alive = [t.is_alive() for t in th]
+    grp_close = not any(alive)
+    if grp_close: grp.close()
+    return cost.sum(axis=1) / len(I), out, err, alive
+
+
+@pytest.mark.parametrize("exchange", ["sync", "overlap"])
+def test_eight_ranks_share_one_gpu(gpu, exchange):
+    """C4's shape (dim 200, fp32 rows, bf16 wire, accumulators every 2nd exchange) with EIGHT contributors per element."""
+    costs, out, err, alive = _run_rank_threads(W8["world"], W8["V"], W8["N"], W8["D"], W8["epochs"], exchange, "bf16")
+    assert not any(alive) and all(e is None for e in err), err
+    for r in range(1, W8["world"]):
+        for k in CTX:
+            assert np.array_equal(out[0][k], out[r][k]), "rank %d's %s differs from rank 0's after replicate()" % (r, k)
+    ref = _oracle8()
+    ratio = np.array(costs) / np.array(ref)
+    print("eight ranks %s D=%d: cost / oracle %s" % (exchange, W8["D"], np.round(ratio, 3).tolist()))
+    assert np.all(np.isfinite(costs)) and np.all(np.diff(costs) < 0)
+    # bands: the blocked order and eight shards shift the first two epochs; from the third the sharded run tracks the
+    # single-process oracle (synchronous: every rank sees the others' moves after each step; overlapped: one step late)
+    np.testing.assert_allclose(costs[:2], ref[:2], rtol=0.25)
+    np.testing.assert_allclose(costs[2:], ref[2:], rtol=0.06 if exchange == "sync" else 0.10)
+
+
+def test_a_failing_rank_releases_its_local_group(gpu):
+    """ADVICE r02: a rank that dies must not leave its peers inside the group's barrier.  Rank 1 leaves before its second epoch;
+    ranks 0 and 2 get GE_ERR_STATE from their next exchange and every thread ends."""
+    costs, out, err, alive = _run_rank_threads(3, 3000, 60_000, 16, 4, "sync", "f32", fail_rank=1)
+    assert not any(alive)
+    assert isinstance(err[1], RuntimeError)
+    from geglove import capi
+    for r in (0, 2):
+        assert isinstance(err[r], capi.GeError) and err[r].status == capi.GE_ERR_STATE, err
+
+
+def test_bench_starts_its_own_ranks(gpu):
+    """`python3 bench.py --gpus 2` from a plain shell (no torchrun): the launcher starts both ranks before any GPU call.  On this
+    one-GPU box they share device 0 over gloo (GE_BENCH_ONE_DEVICE / GE_BENCH_BACKEND, rehearsal switches); the line says n_gpus 2
+    and carries both exchange forms and the per-step cost of the whole job."""
+    import json, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GE_BENCH_BACKEND="gloo", GE_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--rows-per-gpu", "20000", "--nnz-per-gpu", "1500000"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["vocab"] == 40000
+    assert len(d["mean_cost_per_step"]) == 4 and d["mean_cost_per_step"][-1] < d["mean_cost_per_step"][0]
+    assert d["exchange"]["form"] == "overlap" and d["exchange"]["other_form"]["form"] == "sync"
+    assert len(d["exchange"]["other_form"]["mean_cost_per_step"]) == 3
