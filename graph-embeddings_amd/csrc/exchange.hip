@@ -2,7 +2,8 @@
 // single JVM and has no counterpart; the fp32 tables' pass and the all-reduce are in sync.hip).
 //
 //   land:  value += wire - own;  base += wire - own     what the OTHER ranks contributed to the all-reduced sum in `wire`
-//   take:  d = bf16(value - base) (before landing);  wire = own = d;  base += d
+//   take:  d = bf16(value - base) (before landing);  own = d;  base += d      (`wire` is the all-reduce's receive buffer:
+//          the caller sums own -> wire out of place, or copies own into wire and sums in place)
 //
 // `base` is always  consensus + this rank's deltas in flight  (consensus = start + every landed sum, the same on all
 // ranks): what bf16 drops from a delta stays in value - base and goes out with the next one, so the replicas differ only
@@ -77,10 +78,7 @@ __global__ __launch_bounds__(256) void k_exchange_turn_bf16(uint16_t *__restrict
             else reinterpret_cast<uint2 *>(table)[(int64_t)v * stride4 + c4] = make_uint2(t16[0] | (t16[1] << 16), t16[2] | (t16[3] << 16));
         }
         reinterpret_cast<float4 *>(base)[q] = make_float4(b[0], b[1], b[2], b[3]);
-        if (TAKE) {
-            reinterpret_cast<uint2 *>(wire)[q] = make_uint2(w[0] | (w[1] << 16), w[2] | (w[3] << 16));
-            reinterpret_cast<uint2 *>(own)[q]  = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-        }
+        if (TAKE) reinterpret_cast<uint2 *>(own)[q] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
     }
 }
 

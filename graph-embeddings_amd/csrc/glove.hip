@@ -716,8 +716,16 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
             const __amdgpu_buffer_rsrc_t rsN_a = res_rows(id, n_slot, n_a32), rsN_ga = res_gs(id), rsN_ha = res_m2(id);
 #pragma unroll
             for (int q = 0; q < NCH; ++q) {
-                if (EMB16 && !n_a32) aN[q] = emb_load(rsN_a, q);
-                else aN[q] = buf_load<VW, AUX_SC1>(rsN_a, (lane + q * 64) * VW * 4);
+                if constexpr (EMB16) {
+                    // the row lives in one of two places (bf16 table / fp32 master row of a hub): BOTH loads are issued, the one that
+                    // does not apply against a zero-sized resource (no traffic, zeros arrive) -- an `if` around either would put a
+                    // path with no load at all in front of the hand-counted wait of the first step (tests/isa_waits.py)
+                    const __amdgpu_buffer_rsrc_t r16 = make_rsrc(reinterpret_cast<uint16_t *>(A_rows) + (int64_t)id * p.ES, n_a32 ? 0u : (uint32_t)p.D * 2u);
+                    const __amdgpu_buffer_rsrc_t r32 = make_rsrc(p.hub32 + (int64_t)n_slot * D, n_a32 ? (uint32_t)D * 4u : 0u);
+                    VT v16 = emb_load(r16, q), v32 = buf_load<VW, AUX_SC1>(r32, (lane + q * 64) * VW * 4);
+#pragma unroll
+                    for (int t = 0; t < VW; ++t) comp<VW>(aN[q], t) = n_a32 ? comp<VW>(v32, t) : comp<VW>(v16, t);
+                } else aN[q] = buf_load<VW, AUX_SC1>(rsN_a, (lane + q * 64) * VW * 4);
                 gaN[q] = buf_load<VW, AUX_SC1>(rsN_ga, (lane + q * 64) * VW * 4);
                 if constexpr (MOM) haN[q] = buf_load<VW, AUX_SC1>(rsN_ha, (lane + q * 64) * VW * 4);
             }
@@ -838,14 +846,17 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
                 // one store instruction per table covers the row's lanes AND the lane that holds the bias
                 const bool is_bl = FAT && q == bl_q && lane == bl_lane;
                 const bool tail = FAT && !inr[q] && (lane + q * 64) * VW < p.RW;     // the bias lane and the padding behind it: stored too, whole lines go out
-                if (inr[q] || tail) {
+                // The stores below are issued on EVERY path and by every lane: lanes past the row are dropped by the descriptor's
+                // bounds check, not by the exec mask.  A store under `if (lane in range)` sits behind an s_cbranch_execz the
+                // hand-counted wait further up cannot see past (tests/isa_waits.py counts the instructions on every path).
+                {
                     VT ob{}, ogb{}, ohb{};
                     if (tail) {
                         if (is_bl) {
                             comp<VW>(ogb, 0) = ngbb_fat; comp<VW>(ohb, 0) = nhbb_fat;
                             comp<VW>(BIAS_IN_ACC ? ogb : ob, BIAS_C) = nbb_fat;     // (bf16: this lane's row store lies past the bf16 row and is dropped)
                         }
-                    } else {
+                    } else if (inr[q]) {
 #pragma unroll
                         for (int t = 0; t < VW; ++t) {
                             const float av = comp<VW>(a[q], t), bv = comp<VW>(b[q], t);
@@ -871,18 +882,19 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
             }
             if constexpr (!MOM) {
                 const float w2 = wc * wc;
-                if (!FAT && lane == 0) {          // no learning rate on the biases (Adagrad.java:88-89)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, bb - wc * __frsqrt_rn(gbb)), make_rsrc(B_bias + b_id, 4), 0, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gbb + w2), make_rsrc(B_gsb + b_id, 4), 0, 0, AUX_SC1);
+                if constexpr (!FAT) {             // no learning rate on the biases (Adagrad.java:88-89); every lane issues the store, the
+                                                  // 4-byte descriptor keeps lane 0's (no exec-mask branch in front of a counted instruction)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, bb - wc * __frsqrt_rn(gbb)), make_rsrc(B_bias + b_id, 4), lane * 4, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gbb + w2), make_rsrc(B_gsb + b_id, 4), lane * 4, 0, AUX_SC1);
                 }
                 ab = ab - wc * __frsqrt_rn(gab);
                 gab = gab + w2;
             } else {                      // Adam.java:127-145: the biases take the same moment step with gradient wc
                 const float nbb = bb - moment_step(wc, gbb, hbb);
-                if (!FAT && lane == 0) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nbb), make_rsrc(B_bias + b_id, 4), 0, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gbb), make_rsrc(B_gsb + b_id, 4), 0, 0, AUX_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hbb), make_rsrc(B_m2b + b_id, 4), 0, 0, AUX_SC1);
+                if constexpr (!FAT) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, nbb), make_rsrc(B_bias + b_id, 4), lane * 4, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, gbb), make_rsrc(B_gsb + b_id, 4), lane * 4, 0, AUX_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hbb), make_rsrc(B_m2b + b_id, 4), lane * 4, 0, AUX_SC1);
                 }
                 ab = ab - moment_step(wc, gab, hab);
             }
@@ -1176,6 +1188,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     // 49.2 ms on one box and from 60.8 to 54.6 on another (tools/r02/align_probe.sh, kernel_ab.sh).  Rounding further
     // (128 bytes and more) gains nothing at D = 200 and loses 5 % on the 1 216-byte records of bf16 rows.  The padding is never touched.
     if (interleave && !packed) h->ds = (h->ds + 15) / 16 * 16;
+    if (const char *pad = std::getenv("GE_RECORD_PAD_LINES")) if (interleave && !packed) h->ds += 16 * std::max(0, std::atoi(pad));   // experiment: record stride + n x 64 B
     if (emb16) h->es = interleave ? 2 * h->ds : D;
 
     // every failure below frees what the handle owns so far (ge_glove_destroy walks h->owned)
@@ -1209,13 +1222,25 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
                 // does to it is timed on each (0.91 - 0.97 ms on the good placements, 1.04 - 1.11 ms on the others), the fastest is kept.
                 float *blk = nullptr;
                 const size_t bytes = nr * (size_t)h->ds * sizeof(float);
-                // (candidates of one table together stay under 24 GB: allocating and freeing an 8 GB table costs a quarter of a second)
+                const char *alloc_env = std::getenv("GE_TABLE_ALLOC");
+                const bool contiguous = alloc_env && std::strcmp(alloc_env, "contiguous") == 0;
+                // Bounds: the candidates of one table together stay under 24 GB (allocating and freeing an 8 GB table costs a quarter
+                // of a second) AND under half of what the device has free right now (another process may share the GPU; a candidate
+                // that cannot be allocated ends the search with what there is); a table too large for a second candidate gets one.
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+                const size_t budget = std::min<size_t>((size_t)24 << 30, free_b / 2);
                 const int tries = ((cfg->layout_flags & GE_LAYOUT_FIRST_PLACEMENT) || bytes < ((size_t)64 << 20)) ? 1
-                                : (int)std::max<size_t>(2, std::min<size_t>(6, ((size_t)24 << 30) / bytes));
+                                : (int)std::max<size_t>(1, std::min<size_t>(6, budget / bytes));
                 float *cand[6] = {}; float cand_ms[6] = {};
                 int n_cand = 0, best = 0;
                 for (int t = 0; t < tries; ++t) {
-                    hipError_t me = hipMalloc((void **)&cand[t], bytes);
+                    hipError_t me = hipErrorUnknown;
+                    if (contiguous) {                                       // experiment (GE_TABLE_ALLOC=contiguous): physically contiguous VRAM
+                        me = hipExtMallocWithFlags((void **)&cand[t], bytes, hipDeviceMallocContiguous);
+                        if (me != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; }
+                    }
+                    if (me != hipSuccess) me = hipMalloc((void **)&cand[t], bytes);
                     if (me != hipSuccess) { (void)hipGetLastError(); cand[t] = nullptr; break; }     // no room for another candidate: keep what there is
                     ++n_cand;
                     h->owned.push_back((void *)cand[t]);               // the handle owns every candidate until the losers are freed below
@@ -1235,6 +1260,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
                         float slowest = cand_ms[0];
                         for (int u = 1; u <= t; ++u) slowest = std::max(slowest, cand_ms[u]);
                         if (cand_ms[best] < 0.88f * slowest) break;        // both kinds seen and a fast one in hand (they lie 15 - 20 % apart)
+                        if (t >= 2 && cand_ms[best] > 0.98f * slowest) break;  // three candidates within 2 %: a box that has one kind only
                     }
                 }
                 if (n_cand == 0) { ge_status _s = ge::fail(GE_ERR_OOM, "hipMalloc of a %zu-byte record table failed", bytes); ge_glove_destroy(h); return _s; }

@@ -10,8 +10,9 @@
 //   accumulators                               only every cfg.accum_every-th exchange
 // Every fp32 table keeps  base = the consensus c (start + every landed sum, the same bits on every rank)  and  own = this
 // rank's delta in flight; an exchange is
-//   take:  d = narrow(table - c - own in flight);  wire = own = d       (what bf16 drops stays in the table: error feedback)
-//   ---    all-reduce(SUM) of `wire` on the transport's stream, under the next epoch if the caller wishes (ge_sync_turn)
+//   take:  d = narrow(table - c - own in flight);  own = d              (what bf16 drops stays in the table: error feedback)
+//   ---    all-reduce(SUM) own -> wire (out of place: a take writes ONE narrow buffer) on the transport's stream, under the
+//          next epoch if the caller wishes (ge_sync_turn)
 //   land:  c += wire (mean rule: wire / count);  table = c + (table - c_old - own)
 // (bf16 rows go through ge_exchange_turn_bf16, whose base is consensus + own in flight.)
 // The table itself is never on the wire, so the epoch kernel may keep updating it while the all-reduce runs.
@@ -45,7 +46,8 @@ __device__ __forceinline__ uint32_t f32_to_bf16_rne(float f) {
 // own (and cnt) are dense.  base = the CONSENSUS c (start + every landed sum: the same bits on every rank), own = this
 // rank's delta in flight:
 //   land:  c += m (m = wire, or wire / cnt under the mean rule);  resid = (table - c_old) - own;  table = c + resid
-//   take:  d = narrow(resid)  (resid = table - c: the moves not sent yet + what earlier narrowing dropped);  wire = own = d
+//   take:  d = narrow(resid)  (resid = table - c: the moves not sent yet + what earlier narrowing dropped);  own = d
+//          (`wire` is written by the all-reduce alone: send buffer own, receive buffer wire)
 // After a synchronous exchange with an fp32 wire resid is exactly 0, so every rank's table IS c: bit-identical replicas.
 // W16: the wire is bf16.  MEAN: a take also writes cnt = (d != 0), all-reduced beside the wire.
 template <bool LAND, bool TAKE, bool W16, bool MEAN>
@@ -71,10 +73,10 @@ __global__ __launch_bounds__(256) void k_sync_turn(float *__restrict__ table, in
         if (TAKE) {
             if (W16) {
                 const uint32_t h = f32_to_bf16_rne(resid);
-                reinterpret_cast<uint16_t *>(wire_)[k] = (uint16_t)h; reinterpret_cast<uint16_t *>(own_)[k] = (uint16_t)h;
+                reinterpret_cast<uint16_t *>(own_)[k] = (uint16_t)h;
                 if (MEAN) cnt[k] = bf16_to_f32(h) != 0.0f ? 1.0f : 0.0f;
             } else {
-                reinterpret_cast<float *>(wire_)[k] = resid; reinterpret_cast<float *>(own_)[k] = resid;
+                reinterpret_cast<float *>(own_)[k] = resid;
                 if (MEAN) cnt[k] = resid != 0.0f ? 1.0f : 0.0f;
             }
         }
@@ -82,7 +84,8 @@ __global__ __launch_bounds__(256) void k_sync_turn(float *__restrict__ table, in
 }
 
 // The same step for the large tables (cols and the table's row stride multiples of 4, sum rule): one wavefront per row, four
-// elements per lane, 128-bit accesses, no division -- 24 bytes per element for land + take, HBM streaming.
+// elements per lane, 128-bit accesses, no division -- 22 bytes per element for land + take on a bf16 wire (read: table 4,
+// base 4, wire 2, own 2; written: table 4, base 4, own 2), HBM streaming.
 template <bool LAND, bool TAKE, bool W16>
 __global__ __launch_bounds__(256) void k_sync_turn_rows4(float *__restrict__ table, int64_t t_stride, int32_t cols4, int64_t rows,
                                                          float *__restrict__ base, void *__restrict__ wire_, void *__restrict__ own_) {
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(256) void k_sync_turn_rows4(float *__restrict__ tab
                     if (W16) {
                         const uint32_t h0 = f32_to_bf16_rne(res[0]), h1 = f32_to_bf16_rne(res[1]), h2 = f32_to_bf16_rne(res[2]), h3 = f32_to_bf16_rne(res[3]);
                         const uint2 hv = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-                        reinterpret_cast<uint2 *>(wire_)[d] = hv; reinterpret_cast<uint2 *>(own_)[d] = hv;
+                        reinterpret_cast<uint2 *>(own_)[d] = hv;
                     } else {
                         const float4 rv = make_float4(res[0], res[1], res[2], res[3]);
-                        reinterpret_cast<float4 *>(wire_)[d] = rv; reinterpret_cast<float4 *>(own_)[d] = rv;
+                        reinterpret_cast<float4 *>(own_)[d] = rv;
                     }
                 }
             }
@@ -324,6 +327,10 @@ ge_status launch_turn(ge_sync *s, Entry &e, bool land, bool take) {
 // starts the all-reduce of every entry taken in this call
 ge_status start_reduce(ge_sync *s, const std::vector<Entry *> &taken) {
     if (taken.empty()) return GE_OK;
+    // the transports that sum in place (local group, the host's callbacks) get the send buffer copied into the receive buffer
+    // first; RCCL reduces out of place, own -> wire
+    if (s->loop || s->tr.start)
+        for (Entry *e : taken) GE_HIP(hipMemcpyAsync(e->wire, e->own, (size_t)e->n * (e->w16 ? 2 : 4), hipMemcpyDeviceToDevice, s->main));
     if (s->loop) {
         GE_HIP(hipStreamSynchronize(s->main));
         for (Entry *e : taken) {
@@ -335,7 +342,7 @@ ge_status start_reduce(ge_sync *s, const std::vector<Entry *> &taken) {
         GE_HIP(hipEventRecord(s->ev_taken, s->main));
         GE_HIP(hipStreamWaitEvent(s->side, s->ev_taken, 0));
         for (Entry *e : taken) {
-            GE_NCCL(rccl().AllReduce(e->wire, e->wire, (size_t)e->n, e->w16 ? ncclBfloat16 : ncclFloat32, ncclSum, s->comm, s->side));
+            GE_NCCL(rccl().AllReduce(e->own, e->wire, (size_t)e->n, e->w16 ? ncclBfloat16 : ncclFloat32, ncclSum, s->comm, s->side));
             if (e->mean) GE_NCCL(rccl().AllReduce(e->cnt, e->cnt, (size_t)e->n, ncclFloat32, ncclSum, s->comm, s->side));
         }
         GE_HIP(hipEventRecord(s->ev_reduced, s->side));

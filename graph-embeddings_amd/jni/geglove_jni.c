@@ -123,6 +123,10 @@ JNIEXPORT void JNICALL Java_org_uu_nl_embedding_hip_Native_localGroupDestroy(JNI
     (void)env; (void)cls;
     ge_local_group_destroy((ge_local_group *)(intptr_t)group);
 }
+JNIEXPORT void JNICALL Java_org_uu_nl_embedding_hip_Native_localGroupAbort(JNIEnv *env, jclass cls, jlong group) {
+    (void)env; (void)cls;
+    ge_local_group_abort((ge_local_group *)(intptr_t)group);
+}
 /* long syncCreate(long glove, int world, int rank, int wire, int accumEvery, byte[] rcclId (or null), long localGroup (or 0)) */
 JNIEXPORT jlong JNICALL Java_org_uu_nl_embedding_hip_Native_syncCreate(
         JNIEnv *env, jclass cls, jlong glove, jint world, jint rank, jint wire, jint accumEvery, jbyteArray rcclId, jlong localGroup) {
@@ -175,7 +179,11 @@ JNIEXPORT jlong JNICALL Java_org_uu_nl_embedding_hip_Native_bcaBuild(
         jlongArray inPtr, jintArray inIdx, jfloatArray inW, jdouble alpha, jdouble epsilon,
         jboolean directed, jint normalize, jint device, jint rowBegin, jint rowEnd) {
     (void)cls;
+    /* every check that can fail comes BEFORE an array is pinned: an early return must not leave six arrays pinned */
+    if (ge_bca_cfg_size() != (int32_t)sizeof(ge_bca_cfg)) { throw_msg(env, "libgeglove.so and libgeglove_jni.so were built from different revisions of geglove.h"); return 0; }
+    if (!outPtr || !outIdx || !outW || !inPtr || !inIdx || !inW) { throw_msg(env, "bcaBuild: null neighbourhood array"); return 0; }
     ge_csr out, in;
+    memset(&out, 0, sizeof out); memset(&in, 0, sizeof in);
     out.num_vertices = in.num_vertices = V;
     out.ptr = (const int64_t *)(*env)->GetLongArrayElements(env, outPtr, NULL);
     out.idx = (const int32_t *)(*env)->GetIntArrayElements(env, outIdx, NULL);
@@ -183,7 +191,16 @@ JNIEXPORT jlong JNICALL Java_org_uu_nl_embedding_hip_Native_bcaBuild(
     in.ptr = (const int64_t *)(*env)->GetLongArrayElements(env, inPtr, NULL);
     in.idx = (const int32_t *)(*env)->GetIntArrayElements(env, inIdx, NULL);
     in.weight = (*env)->GetFloatArrayElements(env, inW, NULL);
-    if (ge_bca_cfg_size() != (int32_t)sizeof(ge_bca_cfg)) { throw_msg(env, "libgeglove.so and libgeglove_jni.so were built from different revisions of geglove.h"); return 0; }
+    if (!out.ptr || !out.idx || !out.weight || !in.ptr || !in.idx || !in.weight) {      /* the JVM could not pin / copy one of them */
+        if (out.ptr) (*env)->ReleaseLongArrayElements(env, outPtr, (jlong *)out.ptr, JNI_ABORT);
+        if (out.idx) (*env)->ReleaseIntArrayElements(env, outIdx, (jint *)out.idx, JNI_ABORT);
+        if (out.weight) (*env)->ReleaseFloatArrayElements(env, outW, (jfloat *)out.weight, JNI_ABORT);
+        if (in.ptr) (*env)->ReleaseLongArrayElements(env, inPtr, (jlong *)in.ptr, JNI_ABORT);
+        if (in.idx) (*env)->ReleaseIntArrayElements(env, inIdx, (jint *)in.idx, JNI_ABORT);
+        if (in.weight) (*env)->ReleaseFloatArrayElements(env, inW, (jfloat *)in.weight, JNI_ABORT);
+        if (!(*env)->ExceptionCheck(env)) throw_msg(env, "bcaBuild: out of memory while pinning the neighbourhood arrays");
+        return 0;
+    }
     ge_bca_cfg cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.alpha = alpha; cfg.epsilon = epsilon; cfg.directed = directed ? 1 : 0; cfg.normalize = normalize; cfg.device = device;

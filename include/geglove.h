@@ -215,7 +215,7 @@ ge_status ge_glove_set_state(ge_glove *h, int32_t which, const float *in, int64_
 /* Raw device pointer of a table (for zero-copy wrapping by the host runtime, e.g. the
  * torch.distributed/RCCL all-reduce of the context factors). Valid until destroy.
  * GE_MODE_DETERMINISTIC handles: the table as the API shows it, *count floats.  GE_MODE_HOGWILD handles with fp32 rows keep
- * FAT rows (row width dim + 4, a row's bias at [dim]) inside records of ge_context_layout.row_stride floats (row | accumulator
+ * FAT rows (a row's bias at [dim]; row width dim + 4 or the whole lines that hold it) inside records of ge_context_layout.row_stride floats (row | accumulator
  * row | ...): a row table id returns the address of ITS row in the first record and *count = the floats from there to the end
  * of its row in the last record; a bias table id returns the address of row 0's scalar inside the row that carries it (FBIAS ->
  * column [dim] of FOCUS, GSQ_CBIAS -> column [dim] of GSQ_CONTEXT ...; with bf16 rows both scalars follow the accumulator row:
@@ -352,8 +352,10 @@ typedef struct {
     const int32_t *hub_index;    /* [vocab_size], device memory */
     int32_t        n_hub, vocab_size, dim;
     int32_t        row_stride;   /* elements of `table`'s dtype between consecutive rows of `table`.  fp32 GE_MODE_HOGWILD handles keep
-                                    FAT rows (width dim + 4, a row's bias at [dim]) inside records [row | accumulator row]: row_stride =
-                                    2 (dim + 4) floats; bf16 rows lead records [bf16 row padded to 16 B | fp32 accumulator row, fat:
+                                    FAT rows (a row's bias at [dim]; width dim + 4, widened to whole 64-byte lines where that costs under
+                                    10 %: dim 200 -> 208 floats) inside records [row | accumulator row] that start on 64-byte boundaries:
+                                    row_stride = the record, 2 row widths rounded up to 16 floats (dim 200: 416; ge_glove_info.row_stride
+                                    says what a handle uses); bf16 rows lead records [bf16 row padded to 16 B | fp32 accumulator row, fat:
                                     gradSq (dim) | its bias accumulator | the bias | 2 x 0]: row_stride = that record in bf16
                                     elements; GE_LAYOUT_SEPARATE_TABLES: the row width itself */
     float         *accum;        /* gradSqContext (Adam/AMSGrad: M1context); fp32 always; fat like `table` when that is fp32 */
@@ -370,7 +372,8 @@ ge_status ge_glove_context_layout(ge_glove *h, ge_context_layout *out);
  * its parity test).  One pass over device memory on `stream`, asynchronous:
  *   land != 0:  row value += wire - own, base += wire - own   (`wire` = the all-reduced sum of every rank's bf16 delta, `own`
  *               this rank's part of it: the difference is what the others sent);
- *   take != 0:  d = bf16(row value - base) (before landing); wire = own = d; base += d.
+ *   take != 0:  d = bf16(row value - base) (before landing); own = d; base += d.  `wire` is never written here: it is the
+ *               receive buffer of the all-reduce that follows (send buffer own).
  * A row's value lives in hub_rows[hub_index[v]] (fp32 master) when the column is a hub on this rank, else in the bf16 table.
  * The table's rows are `row_stride` bf16 elements apart (a multiple of 4; ge_context_layout.row_stride).
  * `base` is float[vocab_size*dim] for EVERY row (start: the row values widened), wire / own are bf16[vocab_size*dim].  Landed

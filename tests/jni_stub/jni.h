@@ -19,6 +19,7 @@ typedef const struct JNINativeInterface_ *JNIEnv;
 struct JNINativeInterface_ {
     jclass (*FindClass)(JNIEnv *, const char *);
     jint (*ThrowNew)(JNIEnv *, jclass, const char *);
+    jboolean (*ExceptionCheck)(JNIEnv *);
     void (*DeleteLocalRef)(JNIEnv *, jobject);
     jsize (*GetArrayLength)(JNIEnv *, jarray);
     jobject (*GetObjectArrayElement)(JNIEnv *, jobjectArray, jsize);

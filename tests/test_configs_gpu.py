@@ -148,3 +148,86 @@ def test_record_tables_are_placed_by_probing_and_the_choice_changes_no_result(gp
     assert c0 == c1
     for name in s0:
         np.testing.assert_array_equal(s0[name].view(np.uint32), s1[name].view(np.uint32), err_msg=name)
+
+
+# ---- BASELINE C4 / C5 at their own vocabulary on ONE GPU -----------------------------------------------------
+# V = 5 M: a record table is 5 M x 416 floats = 2.08e9 elements (fp32, dim 200) -- every row offset past row 5.16 M / 2 needs the
+# 64-bit row arithmetic of k_init_java, k_adagrad_runs, k_extract and the state copies.  The oracle cannot hold 16 GB of tables in
+# test time, so the checks are the size-independent ones: the Java draw order on sampled rows (an independent Python model of
+# java.util.Random with the jump the kernel uses), one visit per nonzero, a finite and falling cost, extract = (focus + context) / 2.
+_MASK48 = (1 << 48) - 1
+
+
+def _java_rows(seed, D, rows, bf16=False):
+    """Optimizer.java:50-57 for the given rows: per row fB, cB, then foc[d], ctx[d] interleaved, each f(f(d(nextFloat()) - 0.5) / f(D))."""
+    a, c = 0x5DEECE66D, 0xB
+    out = {}
+    for r in rows:
+        n = (2 + 2 * D) * int(r)                    # draws before this row
+        A, Cc, s = 1, 0, (seed ^ a) & _MASK48        # x -> A x + Cc  composed n times by squaring
+        ba, bc = a, c
+        while n:
+            if n & 1:
+                A, Cc = (ba * A) & _MASK48, (ba * Cc + bc) & _MASK48
+            ba, bc = (ba * ba) & _MASK48, (ba * bc + bc) & _MASK48
+            n >>= 1
+        s = (A * s + Cc) & _MASK48
+        vals = np.empty(2 + 2 * D, np.float32)
+        for k in range(2 + 2 * D):
+            s = (s * a + c) & _MASK48
+            nf = np.float32((s >> 24) / float(1 << 24))
+            vals[k] = np.float32(np.float32(np.float64(nf) - 0.5) / np.float32(D))
+        row = {"fbias": vals[0], "cbias": vals[1], "focus": vals[2::2].copy(), "context": vals[3::2].copy()}
+        if bf16:
+            for k in ("focus", "context"):
+                u = row[k].view(np.uint32).astype(np.uint64)
+                row[k] = ((((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16) & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+        out[int(r)] = row
+    return out
+
+
+@pytest.mark.parametrize("D,dtype", [(200, "f32"), (300, "bf16")])
+def test_c4_c5_vocabulary_on_one_gpu(gpu, D, dtype):
+    V = 5_000_000
+    rng = np.random.default_rng(3)
+    # a hub-heavy matrix over the WHOLE id range (rows and columns up to V - 1) + a conflict-free batch to count visits with
+    n_cf = 200_000
+    ci, cj, cx = synth.conflict_free_batch(V, n_cf, seed=21)
+    I, J, X, xmax = synth.synthetic_coo_shard(V, (0, V), 12_000_000, seed=0xC0FFEE)      # the 5 M diagonal entries + 7 M hub-heavy ones
+    assert I.max() == V - 1 and J.max() == V - 1 and len(I) > 11_000_000
+    cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, dtype=dtype)
+    opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+    info = opt.info()
+    assert (V * info["row_stride"] > 2 ** 31) if dtype == "f32" else (V * info["row_stride"] * 2 > 2 ** 31)      # the point of the test
+    # 1. the Java draw order on rows across the whole table, the last one included
+    rows = sorted(set([0, 1, 2_581_110, 2_581_111, V // 2, V - 2, V - 1] + rng.integers(0, V, 12).tolist()))
+    want = _java_rows(42, D, rows, bf16=dtype == "bf16")
+    foc = opt.get_state("focus").reshape(V, D); ctx = opt.get_state("context").reshape(V, D)
+    fb, cb = opt.get_state("fbias"), opt.get_state("cbias")
+    for r in rows:
+        assert np.array_equal(foc[r].view(np.uint32), want[r]["focus"].view(np.uint32)), ("focus row", r)
+        assert np.array_equal(ctx[r].view(np.uint32), want[r]["context"].view(np.uint32)), ("context row", r)
+        assert fb[r] == want[r]["fbias"] and cb[r] == want[r]["cbias"], ("biases of row", r)
+    assert np.all(opt.get_state("gsq_focus").reshape(V, D)[rows] == 1.0)
+    # 2. epochs over the hub-heavy matrix: finite, falling
+    n = len(I)
+    costs = [opt.epoch(it) / n for it in range(3)]
+    print("V=5M D=%d %s: cost %s, kernel %.2f ms, %d workers" % (D, dtype, np.round(costs, 5).tolist(), opt.last_kernel_ms()[0], info["groups_in_flight"]))
+    assert np.all(np.isfinite(costs)) and costs[2] < costs[1] < costs[0]
+    # extract = (focus + context) / 2 on the sampled rows, row V - 1 included (fp32 arithmetic, widened: Optimizer.java:129-140)
+    foc2 = opt.get_state("focus").reshape(V, D); ctx2 = opt.get_state("context").reshape(V, D)
+    ext = opt.extractResult().reshape(V, D)
+    for r in rows:
+        np.testing.assert_array_equal(ext[r], ((foc2[r] + ctx2[r]) / np.float32(2)).astype(np.float64))
+    touched = np.unique(I)
+    g = opt.get_state("gsq_fbias")
+    assert np.all(g[touched] > 1.0) and np.count_nonzero(g != 1.0) == len(touched)
+    del foc, ctx, foc2, ctx2, ext
+    opt.close()
+    # 3. every nonzero visited exactly once, rows and columns spread over the whole range (conflict-free: each update adds wc^2 > 0
+    #    to the bias accumulators of its row and its column, once)
+    opt = geglove.Adagrad(geglove.CooMatrix(V, ci, cj, cx, 0.2), cfg, cfg.costFunction())
+    opt.epoch(0)
+    gf, gc = opt.get_state("gsq_fbias"), opt.get_state("gsq_cbias")
+    assert np.array_equal(np.nonzero(gf != 1.0)[0], np.sort(ci)) and np.array_equal(np.nonzero(gc != 1.0)[0], np.sort(cj))
+    opt.close()

@@ -284,36 +284,49 @@ def test_adam_amsgrad_deterministic_bit_exact(gpu, opt, method, D):
 @pytest.mark.parametrize("opt", ["adam", "amsgrad"])
 @pytest.mark.parametrize("hot", ["none", "auto"])
 @pytest.mark.parametrize("D", [52, 256, 300])      # fat rows in one register chunk; plain rows + bias vectors (lanes full); two chunks
-def test_adam_amsgrad_hogwild_single_worker_replay(gpu, opt, hot, D, monkeypatch):
-    """Hogwild kernel with the moment update rules, one worker, blocked order: sequential replay by the oracle."""
+def test_adam_amsgrad_hogwild_single_worker_replay(gpu, opt, hot, D):
+    """Hogwild kernel with the moment update rules, one worker, blocked order.  A one-worker run is a sequential program, so it is
+    held against two sequential replays of the order it reports:
+      TIGHT  tests/kernel_model.py -- the kernel's OWN fp32 arithmetic in numpy (fma chains per lane, the DPP reduction tree,
+             fp32 moment_step with correctly rounded sqrt and reciprocal): every element of all twelve tables within 1e-5
+             (in practice the same bits; the two `log` implementations may differ in an fp64 ulp);
+      LOOSE  the oracle -- Adam.java's arithmetic (fp64 step).  Adam / AMSGrad steps are lr*m/(sqrt(v)+1e-7): O(lr) per update
+             whatever the gradient, so fp32-vs-fp64 round-off is amplified, most where the second moment is still ~0 and in
+             AMSGrad's unstable first epochs (mean cost 2 -> 14 -> 27 on this matrix): bounded in distribution."""
+    import kernel_model as K
     V, N = 90, 2500
     I, J, X, xmax = synth.synthetic_coo(V, N, seed=17)
     cfg = make_config(D, "glove", opt=opt, mode="hogwild", shuffle="device", seed=5, hot=hot, workers=1, hot_theta=0.02)
     dev = geglove.createOptimizer(cfg, geglove.CooMatrix(V, I, J, X, xmax))
-    ref = {k: np.ascontiguousarray(v.reshape(V, -1) if v.size == V * D else v, np.float32) for k, v in dev.state().items()}
+    info = dev.info()
+    as2d = lambda st: {k: np.ascontiguousarray(v.reshape(V, -1) if v.size == V * D else v, np.float32) for k, v in st.items()}
+    ref = as2d(dev.state())
+    mod = {k: v.copy() for k, v in ref.items()}
     for it in range(2):
         order = dev.epoch_order(it).astype(np.int64)
         cost = dev.epoch(it)
         job = O.opt_job(OPT_KIND[opt], it, D, I[order], J[order], X[order], xmax, O.COST_GLOVE, ref)
+        mcost = K.moment_epoch(opt == "amsgrad", it, D, info["vector_width"], info["chunks_per_lane"], I[order], J[order], X[order], xmax, mod)
+        assert cost == pytest.approx(float(mcost), rel=1e-6)
         assert cost == pytest.approx(float(job), rel=1e-3)
-        # Adam steps are lr*m/(sqrt(v)+1e-7): O(lr) per update whatever the gradient, so fp32 round-off in m and v
-        # (device: fp32 sqrt/rcp, oracle: fp64) is amplified: median error <= 1e-4 (typical 1e-5), 95 % within 5e-3, all within 0.1
-        # AMSGrad's first epochs on this matrix are its unstable phase (mean cost 2 -> 14 -> 27, DESIGN.md 5.3): differences grow
-        # from epoch to epoch there, so its second epoch gets ten times the room (measured: median 2e-4, 95 % 4e-3, max 0.3)
+        got = as2d(dev.state())
+        worst = 0.0
+        for name, g in got.items():
+            g, m = g.reshape(-1), mod[name].reshape(-1)
+            err = np.abs(g - m) / (np.abs(m) + 1e-3 * np.max(np.abs(m)) + 1e-30)
+            worst = max(worst, float(np.max(err)))
+            assert np.max(err) <= 1e-5, ("kernel vs its own arithmetic", name, it, float(np.max(err)), int(np.argmax(err)))
         room = 10.0 if (opt == "amsgrad" and it > 0) else 1.0
-        # Wider rows sum more products per dot (the device reduces across lanes, the oracle adds in order) and hold more elements whose
-        # second moment is still ~0, where a step is +-lr whatever the gradient's size: the same amplification, more of it.  The
-        # elementwise bounds are asserted in full at D = 52; at 256 / 300 the cost (above), the median and the 95th percentile are --
-        # identical figures with the library from before the LDS pipeline (tools/r02/kernel_ab.sh's `head`), so they are arithmetic, not ordering.
-        wide = D > 64
-        if wide:
+        if D > 64:
             room *= 20.0
-        if opt == "amsgrad" and D == 300:          # in its unstable phase from the first epoch on here (median 3e-3, single elements off by
-            continue                               # a factor 20, before and after the LDS pipeline alike): the job cost above is the check
-        for name, got in dev.state().items():
-            g, r = got.reshape(-1), np.asarray(ref[name]).reshape(-1)
-            err = np.abs(g - r) / (np.abs(r) + 1e-3 * np.max(np.abs(r)))
-            assert np.median(err) <= 1e-4 * room and np.quantile(err, 0.95) < 5e-3 * room and (wide or np.max(err) < 0.1 * room), (name, it, float(np.max(err)))
+        stats = []
+        for name, g in got.items():
+            g, r = g.reshape(-1), np.asarray(ref[name]).reshape(-1)
+            err = np.abs(g - r) / (np.abs(r) + 1e-3 * np.max(np.abs(r)) + 1e-30)
+            stats.append((float(np.median(err)), float(np.quantile(err, 0.95)), float(np.max(err))))
+            assert np.median(err) <= 1e-4 * room and np.quantile(err, 0.95) < 5e-3 * room, (name, it, stats[-1])
+        print("%s D=%d hot=%s epoch %d: vs kernel model max %.2e; vs fp64 oracle median %.1e, q95 %.1e, max %.1e"
+              % (opt, D, hot, it, worst, max(s[0] for s in stats), max(s[1] for s in stats), max(s[2] for s in stats)))
 
 
 @pytest.mark.parametrize("opt", ["adam", "amsgrad"])

@@ -63,6 +63,110 @@ def _kernel_metadata():
     return out
 
 
+def _gfx950_code_objects(tmp):
+    """Paths of the gfx950 code objects of libgeglove.so's .hip_fatbin, written under tmp."""
+    objcopy = os.path.join(LLVM, "llvm-objcopy")
+    fat = os.path.join(tmp, "fatbin.bin")
+    subprocess.run([objcopy, "--dump-section", ".hip_fatbin=" + fat, LIB, os.path.join(tmp, "discard")], check=True)
+    blob = open(fat, "rb").read()
+    out, pos = [], 0
+    while True:
+        at = blob.find(MAGIC, pos)
+        if at < 0:
+            return out
+        (count,) = struct.unpack_from("<Q", blob, at + len(MAGIC))
+        cur = at + len(MAGIC) + 8
+        for _ in range(count):
+            offset, size, tlen = struct.unpack_from("<QQQ", blob, cur)
+            cur += 24
+            triple = blob[cur:cur + tlen].decode()
+            cur += tlen
+            if "gfx950" in triple and size:
+                path = os.path.join(tmp, "co%d.elf" % len(out))
+                open(path, "wb").write(blob[at + offset:at + offset + size])
+                out.append(path)
+        pos = at + len(MAGIC)
+
+
+def test_hand_counted_wait_holds_on_every_path():
+    """VERDICT r02 #4 / ADVICE r02: the walk of k_adagrad_runs waits for an LDS image with `s_waitcnt vmcnt(N_AFTER)`, which is long
+    enough only if at least N_AFTER vector-memory instructions follow the image's request on EVERY path (glove.hip, "The wait is
+    counted by hand").  Every instance is disassembled and the minimum over all control-flow paths computed (tests/isa_waits.py);
+    the counted stores are issued unconditionally in the source for exactly this reason (lanes past the row are dropped by the
+    descriptor, not by an exec-mask branch), so the minimum EQUALS N_AFTER -- a compiler or code change that drops, predicates or
+    moves one of them fails here instead of letting a wave read a stale image."""
+    import isa_waits as W
+    objdump = os.path.join(LLVM, "llvm-objdump")
+    if not (os.path.exists(objdump) and os.path.exists(os.path.join(LLVM, "llvm-objcopy"))):
+        pytest.skip("llvm-objdump / llvm-objcopy not found under " + LLVM)
+    if not os.path.exists(LIB):
+        pytest.skip("libgeglove.so not built")
+    seen = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for co in _gfx950_code_objects(tmp):
+            asm = subprocess.run([objdump, "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
+            if "k_adagrad_runs" not in asm:
+                continue
+            for name, ins in W.parse_kernels(asm).items():
+                targs = W.template_args(name)
+                if targs is None:
+                    continue
+                seen += 1
+                n = W.n_after(*targs)
+                group = W.n_tab_dma(*targs)[1]
+                state, problems = W.analyse(ins, group)
+                assert not problems, (name, problems)
+                # the hand-counted waits: vmcnt(N_AFTER) with the image's ds_reads right behind them -- one per unrolled step
+                hand = []
+                for i, (_, mn, ops) in enumerate(ins):
+                    if mn == "s_waitcnt" and W._vmcnt(ops) == n and any(m.startswith("ds_read") for _, m, _ in ins[i + 1:i + 8]):
+                        hand.append(i)
+                assert len(hand) >= 2, "%s: expected vmcnt(%d) in front of the image reads of both unrolled steps, found %d" % (name, n, len(hand))
+                for i in hand:
+                    assert state[i] is not None, (name, i)
+                    k2 = state[i][group]
+                    assert k2 >= n, ("%s: on some path only %d vector-memory instructions follow the request this vmcnt(%d) at %#x waits for"
+                                     % (name, k2, n, ins[i][0]))
+                assert min(state[i][group] for i in hand) == n, (name, "N_AFTER is no longer the tight count", [state[i][group] for i in hand], n)
+                # every wait in front of a read of an image (whatever its immediate) must cover that image's request
+                for i, (_, mn, ops) in enumerate(ins):
+                    if mn == "s_waitcnt" and W._vmcnt(ops) is not None and state[i] is not None and i not in hand:
+                        if any(m.startswith("ds_read_b128") or m.startswith("ds_read_b64") for _, m, _ in ins[i + 1:i + 4]) and W._vmcnt(ops) > n:
+                            assert False, "%s: vmcnt(%d) at %#x in front of LDS reads is looser than N_AFTER = %d" % (name, W._vmcnt(ops), ins[i][0], n)
+                if targs == (4, 1, 0, False, True):                       # the bench instance: nothing of the walk in scratch
+                    assert not any(mn.startswith("scratch_") for _, mn, _ in ins), name
+    assert seen >= 80, "expected every instance of k_adagrad_runs, analysed %d" % seen
+
+
+def test_wait_analysis_sees_a_predicated_store():
+    """The analysis itself, on a six-line loop: one load into LDS per request, one store per step, vmcnt(2) in front of the read.
+    With the store issued unconditionally two instructions follow the request in use on every path; behind an s_cbranch_execz
+    the path that skips it has one, and the wait no longer covers the request."""
+    import isa_waits as W
+
+    def listing(guarded):
+        rows = ["buffer_load_dwordx4 v1, s[0:3], 0 offen lds",        # request image A
+                "buffer_load_dwordx4 v[8:11], v1, s[12:15], 0 offen", # the resident row
+                "buffer_load_dwordx4 v1, s[4:7], 0 offen lds",        # loop: request the other image
+                "s_waitcnt vmcnt(2)",                                   #   wait for this one: the store and the request behind it
+                "ds_read_b128 v[4:7], v2"]
+        rows += ["s_cbranch_execz 1"] if guarded else []
+        rows += ["buffer_store_dwordx4 v[4:7], v1, s[8:11], 0 offen",
+                 "s_cbranch_scc1 %d" % (65536 - (6 if guarded else 5)),  # back to the request
+                 "s_endpgm"]
+        text = "0000000000001000 <k>:\n"
+        for k, r in enumerate(rows):
+            text += "\t%s // %012X: 00000000\n" % (r, 0x1000 + 4 * k)
+        return W.parse_kernels(text)["k"]
+
+    for guarded, want in ((False, 2), (True, 1)):
+        ins = listing(guarded)
+        st, problems = W.analyse(ins, 1)
+        assert not problems
+        wait = [i for i, (_, m, _) in enumerate(ins) if m == "s_waitcnt"][0]
+        assert st[wait][1] == want, (guarded, st[wait])
+
+
 def test_trainer_kernel_instances_keep_their_state_in_registers():
     meta = {k: v for k, v in _kernel_metadata().items() if "k_adagrad_runs" in k}
     assert len(meta) >= 80, "expected every (vector width, chunks, optimiser, bf16, fat) instance, found %d" % len(meta)
