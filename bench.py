@@ -54,6 +54,8 @@ def parse():
                     help="N>1 with --exchange overlap: wavefront slots the epoch kernel leaves free for the all-reduce kernels")
     ap.add_argument("--workers", type=int, default=0, help="sequential workers (wavefronts); 0 = fill the device (cfg.workers)")
     ap.add_argument("--layout", default="", help="comma list of ge_glove_cfg.layout_flags: fixed_cuts, plain_long_rows, separate_tables, packed_records, first_placement (default: none)")
+    ap.add_argument("--hub-segments", type=int, default=0,
+                    help="N>1: small exchanges of the hub rows per epoch (ge_sync_epoch); 0 = the library's default (2 x ranks, at least 8), -1 = none (one exchange per epoch for every row)")
     ap.add_argument("--no-other-form", action="store_true", help="N>1: do not time the other exchange form behind the quoted region")
     ap.add_argument("--accum-sync-every", type=int, default=4, help="every how many context syncs the AdaGrad accumulators are reconciled too (N>1)")
     return ap.parse_args()
@@ -210,7 +212,8 @@ def main():
         sync = parallel.context_sync_for(opt, torch.device("cuda", local_rank), lazy_every=args.accum_sync_every, wire=args.wire)
 
     def step(it, form=None):
-        c = opt.epoch(it)
+        # N > 1: ge_sync_epoch -- the rank's epoch in segments, the hub rows of the context side reconciled behind each
+        c = sync.epoch(it, args.hub_segments) if (sync is not None and args.hub_segments >= 0) else opt.epoch(it)
         if sync is not None and (it + 1) % args.sync_every == 0:
             if (form or args.exchange) == "overlap":
                 sync.turn()                         # lands the deltas sent one exchange ago and sends this step's: the all-reduce runs under the next epoch
@@ -318,9 +321,10 @@ def main():
                                    "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, %s Hogwild, per-epoch device shuffle"
                                    % (world, "s" if world > 1 else "", V, n_local, D, args.method, opt.getName()),
                        "vocab": V, "nnz_per_gpu": n_local, "dim": D, "cost": args.method, "opt": args.opt,
-                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce every %d step(s) (rows summed, biases averaged, accumulators summed every %d syncs, %s on the wire, %s)"
+                       "parallelism": "rows sharded x%d, context replicated + delta all-reduce every %d step(s) (rows summed, biases averaged, accumulators summed every %d syncs, %s on the wire, %s; hub rows reconciled %s per epoch in fp32)"
                                       % (world, args.sync_every, args.accum_sync_every, args.wire,
-                                         "overlapped with the next epoch, %d wavefront slots reserved" % args.reserve_waves if args.exchange == "overlap" else "synchronous")
+                                         "overlapped with the next epoch, %d wavefront slots reserved" % args.reserve_waves if args.exchange == "overlap" else "synchronous",
+                                         ("%d times" % args.hub_segments) if args.hub_segments > 0 else ("max(8, 2 x ranks) times" if args.hub_segments == 0 else "never"))
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "traffic": traffic,

@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <functional>
 #include <memory>
 #include <new>
 #include <vector>
@@ -255,6 +256,127 @@ __device__ bool bca_pass(const BcaParams &p, const BcaWork &w, int32_t bookmark,
     return true;
 }
 
+// ---- the same pass with its hot state in LDS ------------------------------------------------------------------------------------
+// A pop is a chain of dependent table accesses (lowest id of the active list, probe, paint, BCV value, then per neighbour probe /
+// insert / paint); with the tables in global memory every link is a round trip to L2 or HBM -- the per-wave tables of 4 096 waves
+// are 600 MB, far past the caches -- plus a store acknowledgement at every wavefront fence: about twelve round trips, 6.8 us per
+// pop (profiles/r03_bca_*).  Here the table of one bookmark (1 024 slots: key, wet paint, the BCV value and sequence of the pass
+// under way), the active list and the list of used slots live in 20.5 KB of LDS per wavefront (seven wavefronts per CU); what is
+// left in global memory is the graph itself.  paint > 0 <=> the node is in the TreeMap (every paint ever added is >= epsilon > 0).
+// A bookmark that outgrows these bounds (more than 512 nodes touched, or 384 at once in the TreeMap: 0.5 % of the rows of a
+// DBLP-like graph) is left to the global-memory kernel: status 4.
+constexpr int LDS_HC = 1024, LDS_HC_LOG2 = 10, LDS_AC = 384;
+struct BcaHot {
+    int32_t *hkey; double *paint; float *val; int16_t *seq; int32_t *alist; int16_t *touched;
+};
+__device__ __forceinline__ int32_t lds_find(const BcaHot &t, int32_t key) {
+    uint32_t slot = ((uint32_t)key * 2654435761u) >> (32 - LDS_HC_LOG2);
+    for (;;) {
+        if (t.hkey[slot] == key) return (int32_t)slot;
+        slot = (slot + 1) & (uint32_t)(LDS_HC - 1);
+    }
+}
+__device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookmark, int mode, int32_t &n_touched, int32_t &n_seq, int32_t *status) {
+    const int lane = threadIdx.x & 63;
+    const double alpha = p.alpha, epsilon = p.epsilon;
+    int32_t an = 0;
+    auto tree_add = [&](bool act, int32_t nb, double pt) -> bool {
+        int32_t slot = 0; bool inserted = false;
+        if (act) {
+            uint32_t s = ((uint32_t)nb * 2654435761u) >> (32 - LDS_HC_LOG2);
+            for (int probe = 0;; ++probe) {
+                const int32_t k = __hip_atomic_load(t.hkey + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (k == nb) break;
+                if (k == KEY_EMPTY) {
+                    int32_t expected = KEY_EMPTY;
+                    if (__hip_atomic_compare_exchange_strong(t.hkey + s, &expected, nb, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)) { inserted = true; break; }
+                    if (expected == nb) break;
+                }
+                s = (s + 1) & (uint32_t)(LDS_HC - 1);
+                if (probe > LDS_HC) break;
+            }
+            slot = (int32_t)s;
+        }
+        const unsigned long long mi = __ballot(inserted);
+        if (inserted) {
+            const int pos = n_touched + __popcll(mi & lanemask_lt());
+            if (pos < LDS_HC / 2) t.touched[pos] = (int16_t)slot;
+            t.paint[slot] = -1.0; t.seq[slot] = -1;
+        }
+        n_touched += __popcll(mi);
+        if (n_touched > LDS_HC / 2) { if (lane == 0) *status = 4; return false; }
+        bool fresh = false;
+        if (act) {
+            const double cur = t.paint[slot];
+            if (cur > 0) t.paint[slot] = cur + pt;                        // nodeTree.get(n).addPaint(p)
+            else { t.paint[slot] = pt; fresh = true; }                    // nodeTree.put(n, new PaintedNode(n, p))
+        }
+        const unsigned long long mf = __ballot(fresh);
+        if (fresh) {
+            const int pos = an + __popcll(mf & lanemask_lt());
+            if (pos < LDS_AC) t.alist[pos] = nb;
+        }
+        an += __popcll(mf);
+        if (an > LDS_AC) { if (lane == 0) *status = 4; return false; }
+        wave_sync();
+        return true;
+    };
+
+    if (!tree_add(lane == 0, bookmark, 1.0)) return false;
+    while (an > 0) {
+        unsigned long long best = ~0ull;
+        for (int i = lane; i < an; i += 64) {
+            const unsigned long long c = ((unsigned long long)(uint32_t)t.alist[i] << 32) | (uint32_t)i;
+            best = c < best ? c : best;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(best, m, 64); best = o < best ? o : best; }
+        const int32_t focus = rfl((int)(best >> 32));
+        const int32_t fpos = rfl((int)(best & 0xFFFFFFFFull));
+        // the graph reads of this pop do not depend on the table: issued first, they are under way while the table is worked on
+        double total;
+        int64_t ob = 0, oe = 0, ib = 0, ie = 0;
+        if (mode == 0) { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; total = p.g.tot_out[focus]; }
+        else if (mode == 1) { ob = p.g.in_ptr[focus]; oe = p.g.in_ptr[focus + 1]; total = p.g.tot_in[focus]; }
+        else { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; ib = p.g.in_ptr[focus]; ie = p.g.in_ptr[focus + 1]; total = p.g.tot_und[focus]; }
+        if (lane == 0) t.alist[fpos] = t.alist[an - 1];
+        --an;
+        const int32_t fslot = lds_find(t, focus);
+        const double wet = t.paint[fslot];
+        const int32_t old_seq = t.seq[fslot];
+        wave_sync();
+        if (lane == 0) {
+            t.paint[fslot] = -1.0;                                        // pollFirstEntry(): out of the TreeMap
+            const float add = (float)(alpha * wet);                       // bcv.add(focus, (float)(alpha * wet))
+            if (old_seq < 0) { t.seq[fslot] = (int16_t)n_seq; t.val[fslot] = 0.0f + add; }
+            else t.val[fslot] = t.val[fslot] + add;
+        }
+        if (old_seq < 0) ++n_seq;
+        wave_sync();
+        if (wet < epsilon) continue;
+        if (mode != 2) {
+            if (oe == ob) continue;
+            if (total == 0) continue;
+        }
+        const double spread = (1 - alpha) * wet;
+        const int32_t *idx0 = mode == 1 ? p.g.in_idx : p.g.out_idx;
+        const float *w0 = mode == 1 ? p.g.in_w : p.g.out_w;
+        for (int64_t k = ob; k < oe; k += 64) {
+            const int64_t kk = k + lane;
+            bool act = kk < oe; int32_t nb = 0; double pt = 0;
+            if (act) { nb = idx0[kk]; const float weight = w0[kk]; pt = spread * ((double)weight / total); act = !(pt < epsilon); }
+            if (!tree_add(act, nb, pt)) return false;
+        }
+        for (int64_t k = ib; k < ie; k += 64) {
+            const int64_t kk = k + lane;
+            bool act = kk < ie; int32_t nb = 0; double pt = 0;
+            if (act) { nb = p.g.in_idx[kk]; const float weight = p.g.in_w[kk]; pt = spread * ((double)weight / total); act = !(pt < epsilon); }
+            if (!tree_add(act, nb, pt)) return false;
+        }
+    }
+    return true;
+}
+
 // Float.compare-based max/min over a row (BCV.max / BCV.min)
 __device__ __forceinline__ int float_compare(float a, float b) {
     if (a < b) return -1;
@@ -299,12 +421,23 @@ __device__ __forceinline__ gejm::Map exact_map(const BcaParams &p, const BcaWork
     return m;
 }
 
+// LDS: the passes run on the LDS tables above and hand their result to the global workspace `w`, where the emission below finds
+// it exactly as the global-memory passes leave it (p.hc = LDS_HC then).
+template <bool LDS>
 __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x;
     const BcaWork w = carve(p, wave);
+    __shared__ double s_paint[LDS ? LDS_HC : 1];
+    __shared__ int32_t s_hkey[LDS ? LDS_HC : 1];
+    __shared__ float s_val[LDS ? LDS_HC : 1];
+    __shared__ int32_t s_alist[LDS ? LDS_AC : 1];
+    __shared__ int16_t s_seq[LDS ? LDS_HC : 1];
+    __shared__ int16_t s_touched[LDS ? LDS_HC / 2 : 1];
+    const BcaHot hot{s_hkey, s_paint, s_val, s_seq, s_alist, s_touched};
     // table starts empty
-    for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY;
+    if constexpr (LDS) { for (int i = lane; i < LDS_HC; i += 64) s_hkey[i] = KEY_EMPTY; }
+    else { for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY; }
     wave_sync();
     for (;;) {
         unsigned long long ticket = 0;
@@ -315,9 +448,40 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
         const int32_t bookmark = p.row_begin + r;
         int32_t n_touched = 0, nf = 0, nr = 0;
         int32_t status = 0;
-        bool ok = bca_pass(p, w, bookmark, p.directed ? 0 : 2, false, n_touched, nf, &status);
-        if (ok && p.directed) ok = bca_pass(p, w, bookmark, 1, true, n_touched, nr, &status);   // DirectedWeighted: reverse = true always
+        bool ok;
+        if constexpr (LDS) {
+            ok = bca_pass_lds(p, hot, bookmark, p.directed ? 0 : 2, n_touched, nf, &status);
+            const int32_t nt_f = n_touched;
+            if (ok) {                                      // the forward BCV leaves LDS: slot list, keys, values, sequences
+                for (int e = lane; e < nt_f; e += 64) {
+                    const int32_t sl = s_touched[e];
+                    w.touched[e] = sl; w.hkey[sl] = s_hkey[sl]; w.fval[sl] = s_val[sl]; w.fseq[sl] = s_seq[sl]; w.rseq[sl] = -1;
+                    s_seq[sl] = -1;                        // the reverse pass keeps its own BCV
+                }
+                wave_sync();
+            }
+            if (ok && p.directed) {
+                ok = bca_pass_lds(p, hot, bookmark, 1, n_touched, nr, &status);   // DirectedWeighted: reverse = true always
+                if (ok) {
+                    for (int e = lane; e < n_touched; e += 64) {
+                        const int32_t sl = s_touched[e];
+                        if (e >= nt_f) { w.touched[e] = sl; w.hkey[sl] = s_hkey[sl]; w.fseq[sl] = -1; }   // first seen by the reverse pass
+                        w.rval[sl] = s_val[sl]; w.rseq[sl] = s_seq[sl];
+                    }
+                    wave_sync();
+                }
+            }
+        } else {
+            ok = bca_pass(p, w, bookmark, p.directed ? 0 : 2, false, n_touched, nf, &status);
+            if (ok && p.directed) ok = bca_pass(p, w, bookmark, 1, true, n_touched, nr, &status);   // DirectedWeighted: reverse = true always
+        }
         status = rfl(status);
+        if (LDS && !ok && status == 4) {                   // outgrew the LDS tables: the global-memory kernel runs this bookmark
+            if (lane == 0) { p.row_n[r] = 0; p.row_off[r] = -2; p.row_max[r] = 1.0f; atomicMax(p.status, 4); }
+            for (int i = lane; i < LDS_HC; i += 64) s_hkey[i] = KEY_EMPTY;
+            wave_sync();
+            continue;
+        }
         int32_t n_out = 0; float row_max = 1.0f;
         int64_t off = 0;
         if (ok) {
@@ -461,7 +625,8 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
             if (off + n_out > p.out_cap) { fits = false; }      // the row size is known: it is re-run alone into an exact pool
             if (!fits) {
                 if (lane == 0) { p.row_n[r] = n_out; p.row_off[r] = -1; p.row_max[r] = 1.0f; atomicMax(p.status, 3); }
-                for (int e = lane; e < n_touched && e < p.hc / 2; e += 64) w.hkey[w.touched[e]] = KEY_EMPTY;
+                if constexpr (LDS) { for (int e = lane; e < n_touched; e += 64) s_hkey[s_touched[e]] = KEY_EMPTY; }
+                else { for (int e = lane; e < n_touched && e < p.hc / 2; e += 64) w.hkey[w.touched[e]] = KEY_EMPTY; }
                 wave_sync();
                 continue;
             }
@@ -523,13 +688,16 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
         }
         if (lane == 0) {
             p.row_n[r] = ok ? n_out : 0;
-            p.row_off[r] = off;
+            p.row_off[r] = (LDS && !ok) ? -2 : off;                   // (the LDS kernel's tables do not grow: the other kernel takes the row)
             p.row_max[r] = row_max;
-            if (!ok) atomicMax(p.status, status ? status : 1);
+            if (!ok) atomicMax(p.status, LDS ? 4 : (status ? status : 1));
         }
         // reset the table for the next bookmark
-        for (int e = lane; e < n_touched && e < p.hc / 2; e += 64) w.hkey[w.touched[e]] = KEY_EMPTY;
-        if (!ok && status == 1) for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY;   // touched[] was truncated
+        if constexpr (LDS) { for (int e = lane; e < n_touched && e < LDS_HC / 2; e += 64) s_hkey[s_touched[e]] = KEY_EMPTY; }
+        else {
+            for (int e = lane; e < n_touched && e < p.hc / 2; e += 64) w.hkey[w.touched[e]] = KEY_EMPTY;
+            if (!ok && status == 1) for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY;   // touched[] was truncated
+        }
         wave_sync();
     }
 }
@@ -673,109 +841,141 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     p.row_n = d_row_n; p.row_off = d_row_off; p.row_max = d_row_max;
     p.pool_used = d_ctr; p.queue = d_ctr + 1; p.status = reinterpret_cast<int32_t *>(d_ctr + 2);
 
-    // capacities: the TreeMap never holds more than 1/epsilon nodes (every node in it carries >= epsilon of at
-    // most 1.0 paint); the table holds every node touched by the forward+reverse passes.  Both grow on overflow.
+    // ---- the passes ---------------------------------------------------------------------------------------------------------
+    // Main launch: the LDS kernel (k_bca<true>: 1 024-slot tables per wavefront in LDS, seven wavefronts per CU) over every
+    // bookmark into a pool whose size comes from a sample.  What it leaves: rows that did not fit the pool (size known) and
+    // bookmarks that outgrew the LDS tables (status 4, size unknown).  Those are run by the global-memory kernel (k_bca<false>,
+    // tables that grow on overflow): first without a pool, to learn their sizes, then -- together with the rows the pool had no
+    // room for -- into a second pool of exactly the missing size.  cfg.table_slots > 0 (tests) or GE_BCA_TABLES=global: the
+    // global-memory kernel does everything, as before round 3.
+    const char *tables_env = std::getenv("GE_BCA_TABLES");
+    const bool use_lds = cfg->table_slots == 0 && !(tables_env && std::strcmp(tables_env, "global") == 0);
+    // global-memory tables: the TreeMap never holds more than 1/epsilon nodes (every node in it carries >= epsilon of at most 1.0
+    // paint); the table holds every node touched by the forward+reverse passes.  Both grow on overflow.
     int64_t ac = (int64_t)std::min<double>((double)V, std::ceil(1.0 / cfg->epsilon) + 2.0) + 64;
     int64_t hc = 2048;
     while (hc < 4 * std::min<int64_t>(V, 256)) hc <<= 1;
+    if (cfg->table_slots > 0) hc = std::max<int64_t>(64, cfg->table_slots);
     int64_t pool_cap = std::max<int64_t>((int64_t)n_rows * 128, 1 << 16);
-    // Large builds size the pool from a sample first: 2048 evenly spaced bookmarks are run with an empty pool (every
-    // row reports its size, none is stored), the mean row size + 25 % decides.  < 1 % extra work instead of re-running
-    // the rows a wrong guess leaves out.
     bool sampled = n_rows <= 16384;
     if (cfg->pool_entries > 0) { pool_cap = std::max<int64_t>(64, cfg->pool_entries); sampled = true; }
-    int32_t *d_sample = nullptr; int32_t n_sample = 0;
-    if (cfg->table_slots > 0) hc = std::max<int64_t>(64, cfg->table_slots);
-    int32_t *d_pJ = nullptr; float *d_pX = nullptr; char *d_work = nullptr;
+    int32_t *d_pJ = nullptr, *d_pJ2 = nullptr; float *d_pX = nullptr, *d_pX2 = nullptr;
     std::vector<int32_t> h_n((size_t)n_rows);
-    // Rows are written into a pool whose size is a guess; a row that does not fit still reports its size, and only
-    // those rows are run again into a second pool of exactly the missing size (no bookmark is computed twice in vain
-    // unless a WORK table overflows, in which case everything is repeated with larger tables).
-    int32_t *d_pJ2 = nullptr; float *d_pX2 = nullptr; int32_t *d_redo = nullptr;
     std::vector<int64_t> h_off((size_t)n_rows);
+
+    struct Work { char *mem = nullptr; int64_t hc = 0, ac = 0, stride = 0, n_waves = 0; bool lds = false; };
+    auto free_work = [&](Work &w) { if (w.mem) { (void)hipFree(w.mem); w.mem = nullptr; } };
+    auto make_work = [&](Work &w, bool lds) -> ge_status {
+        free_work(w);
+        w.lds = lds;
+        if (lds) { w.hc = LDS_HC; w.ac = LDS_AC; }
+        else { int hl = 0; while ((1ll << hl) < hc) ++hl; hc = 1ll << hl; w.hc = hc; w.ac = ac; }
+        w.stride = (work_bytes(w.hc, w.ac) + 255) / 256 * 256;
+        w.n_waves = std::min<int64_t>((int64_t)cus * (lds ? 7 : 16), n_rows);
+        while (w.n_waves > 1 && w.n_waves * w.stride > (int64_t)6 << 30) w.n_waves /= 2;
+        if (hipMalloc((void **)&w.mem, (size_t)(w.n_waves * w.stride)) != hipSuccess) {
+            (void)hipGetLastError(); w.mem = nullptr;
+            return ge::fail(GE_ERR_OOM, "device allocation failed for BCA work buffers (table %lld slots x %lld waves)", (long long)w.hc, (long long)w.n_waves);
+        }
+        return GE_OK;
+    };
+    // one launch over `n_jobs` bookmarks (all rows, or the list `jobs`); returns the status word, *used = entries taken from the pool
+    auto run = [&](const Work &w, const int32_t *jobs, int32_t n_jobs, int32_t *oJ, float *oX, int64_t out_cap, unsigned long long used0,
+                   int32_t *status, unsigned long long *used) -> ge_status {
+        int hl = 0; while ((1ll << hl) < w.hc) ++hl;
+        p.hc = (int32_t)w.hc; p.hc_log2 = hl; p.ac = (int32_t)w.ac; p.work = w.mem; p.work_stride = w.stride;
+        p.outJ = oJ; p.outX = oX; p.out_cap = out_cap; p.redo = jobs; p.n_jobs = n_jobs;
+        unsigned long long h_ctr[4] = {used0, 0, 0, 0};
+        hipError_t e = hipMemcpy(d_ctr, h_ctr, 32, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>(w.n_waves, n_jobs))), b(64);
+            if (w.lds) hipLaunchKernelGGL(k_bca<true>, g, b, 0, 0, p); else hipLaunchKernelGGL(k_bca<false>, g, b, 0, 0, p);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(h_ctr, d_ctr, 32, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return ge::fail(GE_ERR_HIP, "BCA kernel failed: %s", hipGetErrorString(e));
+        *status = (int32_t)(h_ctr[2] & 0xFFFFFFFFull); *used = h_ctr[0];
+        return GE_OK;
+    };
+    struct Guard { std::function<void()> f; ~Guard() { f(); } };
+    Work wmain, wglob;
+    Guard work_guard{[&] { free_work(wmain); free_work(wglob); }};
+    auto grow = [&](int32_t status) { if (status == 1) hc *= 4; else ac = std::min<int64_t>(ac * 4, (int64_t)V + 64); };
+
+    int32_t status = 0; unsigned long long used = 0;
     for (int attempt = 0;; ++attempt) {
         if (attempt > 12) return ge::fail(GE_ERR_OVERFLOW, "BCA work buffers kept overflowing (table %lld, active list %lld, pool %lld)", (long long)hc, (long long)ac, (long long)pool_cap);
-        int hl = 0; while ((1ll << hl) < hc) ++hl;
-        hc = 1ll << hl;
-        const int64_t stride = (work_bytes(hc, ac) + 255) / 256 * 256;
-        int64_t n_waves = std::min<int64_t>((int64_t)cus * 16, n_rows);
-        while (n_waves > 1 && n_waves * stride > (int64_t)6 << 30) n_waves /= 2;
-        if (d_work) { (void)hipFree(d_work); d_work = nullptr; }
-        if (d_pJ) { (void)hipFree(d_pJ); d_pJ = nullptr; }
-        if (d_pX) { (void)hipFree(d_pX); d_pX = nullptr; }
-        hipError_t e1 = hipMalloc((void **)&d_work, (size_t)(n_waves * stride));
-        if (e1 == hipSuccess && !sampled) {
-            if (!d_sample) {
-                n_sample = 2048;
-                std::vector<int32_t> rows((size_t)n_sample);
-                for (int32_t k = 0; k < n_sample; ++k) rows[(size_t)k] = (int32_t)((int64_t)k * n_rows / n_sample);
-                if (hipMalloc((void **)&d_sample, sizeof(int32_t) * (size_t)n_sample) != hipSuccess) { (void)hipFree(d_work); return ge::fail(GE_ERR_OOM, "device allocation failed for the BCA sample"); }
-                dev.keep(d_sample);
-                if (hipMemcpy(d_sample, rows.data(), sizeof(int32_t) * (size_t)n_sample, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_work); return ge::fail(GE_ERR_HIP, "BCA sample upload failed"); }
-            }
-            p.hc = (int32_t)hc; p.hc_log2 = hl; p.ac = (int32_t)ac; p.work = d_work; p.work_stride = stride;
-            p.outJ = nullptr; p.outX = nullptr; p.out_cap = 0; p.redo = d_sample; p.n_jobs = n_sample;
-            hipError_t e = hipMemset(d_ctr, 0, 32);
-            if (e == hipSuccess) { hipLaunchKernelGGL(k_bca, dim3((unsigned)std::min<int64_t>(n_waves, n_sample)), dim3(64), 0, 0, p); e = hipGetLastError(); }
-            if (e == hipSuccess) e = hipDeviceSynchronize();
-            unsigned long long h_s[4] = {0, 0, 0, 0};
-            if (e == hipSuccess) e = hipMemcpy(h_s, d_ctr, 32, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) { (void)hipFree(d_work); return ge::fail(GE_ERR_HIP, "BCA sample pass failed: %s", hipGetErrorString(e)); }
-            const int32_t st = (int32_t)(h_s[2] & 0xFFFFFFFFull);
-            if (st == 1) { hc *= 4; continue; }
-            if (st == 2) { ac = std::min<int64_t>(ac * 4, (int64_t)V + 64); continue; }
-            const double mean = (double)h_s[0] / (double)n_sample;           // pool_used counted every sampled row
+        if ((st = make_work(wmain, use_lds)) != GE_OK) return st;
+        if (!sampled) {
+            // Large builds size the pool from a sample first: 2048 evenly spaced bookmarks are run without a pool (every row reports
+            // its size, none is stored), the mean row size + 25 % decides.  < 1 % extra work instead of re-running what a wrong guess leaves out.
+            const int32_t n_sample = 2048;
+            std::vector<int32_t> rows((size_t)n_sample);
+            for (int32_t k = 0; k < n_sample; ++k) rows[(size_t)k] = (int32_t)((int64_t)k * n_rows / n_sample);
+            int32_t *d_sample = nullptr;
+            if (hipMalloc((void **)&d_sample, sizeof(int32_t) * (size_t)n_sample) != hipSuccess) return ge::fail(GE_ERR_OOM, "device allocation failed for the BCA sample");
+            dev.keep(d_sample);
+            GE_HIP(hipMemcpy(d_sample, rows.data(), sizeof(int32_t) * (size_t)n_sample, hipMemcpyHostToDevice));
+            if ((st = run(wmain, d_sample, n_sample, nullptr, nullptr, 0, 0, &status, &used)) != GE_OK) return st;
+            if (!use_lds && (status == 1 || status == 2)) { grow(status); continue; }
+            const double mean = (double)used / (double)n_sample;            // pool_used counted every sampled row that ran through
             pool_cap = std::max<int64_t>(1 << 16, (int64_t)(mean * 1.25 * (double)n_rows) + 65536);
             sampled = true;
         }
-        hipError_t e2 = hipMalloc((void **)&d_pJ, sizeof(int32_t) * (size_t)pool_cap);
-        hipError_t e3 = hipMalloc((void **)&d_pX, sizeof(float) * (size_t)pool_cap);
-        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
-            if (d_work) (void)hipFree(d_work);
+        if (d_pJ) { (void)hipFree(d_pJ); d_pJ = nullptr; }
+        if (d_pX) { (void)hipFree(d_pX); d_pX = nullptr; }
+        if (hipMalloc((void **)&d_pJ, sizeof(int32_t) * (size_t)pool_cap) != hipSuccess || hipMalloc((void **)&d_pX, sizeof(float) * (size_t)pool_cap) != hipSuccess) {
+            (void)hipGetLastError();
             if (d_pJ) (void)hipFree(d_pJ);
             if (d_pX) (void)hipFree(d_pX);
-            return ge::fail(GE_ERR_OOM, "device allocation failed for BCA work buffers (table %lld slots x %lld waves, pool %lld)", (long long)hc, (long long)n_waves, (long long)pool_cap);
+            return ge::fail(GE_ERR_OOM, "device allocation failed for the BCA pool (%lld entries)", (long long)pool_cap);
         }
-        p.hc = (int32_t)hc; p.hc_log2 = hl; p.ac = (int32_t)ac; p.work = d_work; p.work_stride = stride;
-        p.outJ = d_pJ; p.outX = d_pX; p.out_cap = pool_cap; p.redo = nullptr; p.n_jobs = n_rows;
-        hipError_t e = hipMemset(d_ctr, 0, 32);
-        if (e == hipSuccess) { hipLaunchKernelGGL(k_bca, dim3((unsigned)n_waves), dim3(64), 0, 0, p); e = hipGetLastError(); }
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        unsigned long long h_ctr[4] = {0, 0, 0, 0};
-        if (e == hipSuccess) e = hipMemcpy(h_ctr, d_ctr, 32, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_HIP, "BCA kernel failed: %s", hipGetErrorString(e)); }
-        const int32_t status = (int32_t)(h_ctr[2] & 0xFFFFFFFFull);
-        if (status == 0) break;
-        if (status == 1) { hc *= 4; continue; }
-        if (status == 2) { ac = std::min<int64_t>(ac * 4, (int64_t)V + 64); continue; }
-        // status 3: some rows did not fit.  Re-run exactly those into a pool of exactly their size.
-        e = hipMemcpy(h_n.data(), d_row_n, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(h_off.data(), d_row_off, sizeof(int64_t) * (size_t)n_rows, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_HIP, "copy back failed: %s", hipGetErrorString(e)); }
-        std::vector<int32_t> redo; int64_t need = 0;
-        for (int32_t r = 0; r < n_rows; ++r) if (h_off[(size_t)r] < 0) { redo.push_back(r); need += h_n[(size_t)r]; }
-        const int64_t cap2 = need + 64;
-        bool good = hipMalloc((void **)&d_pJ2, sizeof(int32_t) * (size_t)cap2) == hipSuccess;
-        good = good && hipMalloc((void **)&d_pX2, sizeof(float) * (size_t)cap2) == hipSuccess;
-        good = good && hipMalloc((void **)&d_redo, sizeof(int32_t) * redo.size()) == hipSuccess;
-        if (d_pJ2) dev.keep(d_pJ2);
-        if (d_pX2) dev.keep(d_pX2);
-        if (d_redo) dev.keep(d_redo);
-        if (!good) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_OOM, "device allocation failed for the second BCA pool (%lld entries)", (long long)cap2); }
-        e = hipMemcpy(d_redo, redo.data(), sizeof(int32_t) * redo.size(), hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemset(d_ctr, 0, 32);
-        // second-pool offsets are stored shifted by pool_cap so that one gather kernel can tell the pools apart
-        p.outJ = d_pJ2 - pool_cap; p.outX = d_pX2 - pool_cap; p.out_cap = pool_cap + cap2; p.redo = d_redo; p.n_jobs = (int32_t)redo.size();
-        unsigned long long used0 = (unsigned long long)pool_cap;
-        if (e == hipSuccess) e = hipMemcpy(d_ctr, &used0, 8, hipMemcpyHostToDevice);
-        if (e == hipSuccess) { hipLaunchKernelGGL(k_bca, dim3((unsigned)std::min<int64_t>(n_waves, (int64_t)redo.size())), dim3(64), 0, 0, p); e = hipGetLastError(); }
-        if (e == hipSuccess) e = hipDeviceSynchronize();
-        if (e == hipSuccess) e = hipMemcpy(h_ctr, d_ctr, 32, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_HIP, "BCA kernel (second pool) failed: %s", hipGetErrorString(e)); }
-        if ((int32_t)(h_ctr[2] & 0xFFFFFFFFull) != 0) { (void)hipFree(d_work); (void)hipFree(d_pJ); (void)hipFree(d_pX); return ge::fail(GE_ERR_OVERFLOW, "BCA second pool overflowed (internal sizing error)"); }
+        if ((st = run(wmain, nullptr, n_rows, d_pJ, d_pX, pool_cap, 0, &status, &used)) != GE_OK) { (void)hipFree(d_pJ); (void)hipFree(d_pX); return st; }
+        if (!use_lds && (status == 1 || status == 2)) { grow(status); continue; }
         break;
     }
-    dev.keep(d_work); dev.keep(d_pJ); dev.keep(d_pX);
+    dev.keep(d_pJ); dev.keep(d_pX);
+    if (status != 0) {
+        // rows left over: no room in the pool (row_off -1, size in row_n) or too large for the LDS tables (row_off -2, size unknown)
+        GE_HIP(hipMemcpy(h_n.data(), d_row_n, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost));
+        GE_HIP(hipMemcpy(h_off.data(), d_row_off, sizeof(int64_t) * (size_t)n_rows, hipMemcpyDeviceToHost));
+        std::vector<int32_t> redo, big;
+        for (int32_t r = 0; r < n_rows; ++r) if (h_off[(size_t)r] < 0) { redo.push_back(r); if (h_off[(size_t)r] == -2) big.push_back(r); }
+        int32_t *d_redo = nullptr;
+        GE_HIP(hipMalloc((void **)&d_redo, sizeof(int32_t) * std::max<size_t>(redo.size(), 1))); dev.keep(d_redo);
+        const Work *wredo = &wmain;
+        if (!big.empty()) {
+            // the global-memory kernel learns the sizes of the big rows (no pool: every row reports its size), growing its tables as needed
+            GE_HIP(hipMemcpy(d_redo, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice));
+            for (int attempt = 0;; ++attempt) {
+                if (attempt > 12) return ge::fail(GE_ERR_OVERFLOW, "BCA work buffers kept overflowing (table %lld, active list %lld)", (long long)hc, (long long)ac);
+                if ((st = make_work(wglob, false)) != GE_OK) return st;
+                if ((st = run(wglob, d_redo, (int32_t)big.size(), nullptr, nullptr, 0, 0, &status, &used)) != GE_OK) return st;
+                if (status == 1 || status == 2) { grow(status); continue; }
+                break;
+            }
+            GE_HIP(hipMemcpy(h_n.data(), d_row_n, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost));
+            wredo = &wglob;
+        }
+        int64_t need = 0;
+        for (int32_t r : redo) need += h_n[(size_t)r];
+        const int64_t cap2 = need + 64;
+        bool good = hipMalloc((void **)&d_pJ2, sizeof(int32_t) * (size_t)cap2) == hipSuccess;
+        if (d_pJ2) dev.keep(d_pJ2);
+        good = good && hipMalloc((void **)&d_pX2, sizeof(float) * (size_t)cap2) == hipSuccess;
+        if (d_pX2) dev.keep(d_pX2);
+        if (!good) return ge::fail(GE_ERR_OOM, "device allocation failed for the second BCA pool (%lld entries)", (long long)cap2);
+        GE_HIP(hipMemcpy(d_redo, redo.data(), sizeof(int32_t) * redo.size(), hipMemcpyHostToDevice));
+        // second-pool offsets are stored shifted by pool_cap so that one gather kernel can tell the pools apart
+        for (int attempt = 0;; ++attempt) {
+            if (attempt > 12) return ge::fail(GE_ERR_OVERFLOW, "BCA work buffers kept overflowing (table %lld, active list %lld)", (long long)hc, (long long)ac);
+            if ((st = run(*wredo, d_redo, (int32_t)redo.size(), d_pJ2 - pool_cap, d_pX2 - pool_cap, pool_cap + cap2, (unsigned long long)pool_cap, &status, &used)) != GE_OK) return st;
+            if (!wredo->lds && (status == 1 || status == 2)) { grow(status); if ((st = make_work(wglob, false)) != GE_OK) return st; wredo = &wglob; continue; }
+            break;
+        }
+        if (status != 0) return ge::fail(GE_ERR_OVERFLOW, "BCA second pool overflowed (internal sizing error, status %d)", status);
+    }
     clk.lap("upload + k_bca passes");
 
     ge_coo *c = new (std::nothrow) ge_coo();

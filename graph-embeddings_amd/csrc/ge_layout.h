@@ -47,6 +47,7 @@ struct BlockedLayout {
     int32_t flush_min = LAYOUT_CHUNK;
     int64_t long_rows = 0, shared_chunks = 0;
     int64_t n_runs = 0;              // runs per epoch: times a resident row (+ its accumulator row) is loaded and published
+    std::vector<int32_t> hubs;       // the hub columns, ascending
     std::vector<int32_t> hub_index;  // [V] dense hub index or -1 (want_hub_index)
     int32_t n_hub = 0;
     void release();                  // frees the device arrays

@@ -45,6 +45,7 @@ struct GloveParams {
     const float *W;        // Hogwild: per-nonzero weight
     const int32_t *bA, *bB;   // Hogwild, blocked order: resident / streamed row id per re-ordered position
     int64_t n_chunks;         // chunks of <= RUN_CHUNK nonzeros per epoch
+    int64_t ticket_end;       // this launch hands out the tickets below this one (n_chunks: the whole epoch; less: one segment of it)
     int64_t n_hchunks;        // blocked order: the first n_hchunks chunks are hub columns (column-major)
     int32_t blocked;          // 1: chunk c = positions [cstart[c], cstart[c+1]) of the re-ordered arrays (ge_layout.h)
     int32_t hot_enabled;      // blocked order: hub chunks publish deltas with atomics
@@ -443,7 +444,9 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
         m = __builtin_fmaf(BETA1, m, OMB1 * grad);
         const float vn = __builtin_fmaf(BETA2, v, OMB2 * (grad * grad));
         v = OPT == GE_OPT_AMSGRAD ? fmaxf(v, vn) : vn;
-        return corr * m * __frcp_rn(__fsqrt_rn(v) + EPS);
+        // IEEE operations only (fma, mul, add, correctly rounded sqrt and division: HIP's default for fp32 without fast-math), so that
+        // tests/kernel_model.py can restate this arithmetic bit for bit; __fsqrt_rn is the 1-ulp v_sqrt_f32 in this toolchain
+        return corr * m * (1.0f / (__builtin_sqrtf(v) + EPS));
     };
     const int lane = threadIdx.x & 63;
     const int32_t D = p.D;
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
         unsigned long long ticket = 0;
         if (lane == 0) ticket = atomicAdd(p.queue, 1ull);
         const int64_t tk = ((int64_t)(unsigned)rfl((int)(ticket >> 32)) << 32) | (unsigned)rfl((int)(ticket & 0xFFFFFFFFull));
-        if (tk >= n_chunks) break;
+        if (tk >= p.ticket_end) break;          // (the queue starts at the segment's first ticket, glove_epoch_segment)
 
         // ---- stage: two nonzeros per lane ------------------------------------------------------
         // key = id of the RESIDENT row (sorted on, kept in registers across a run), oth = id of the
@@ -1015,6 +1018,7 @@ struct ge_glove {
     float place_best_ms = 0.0f, place_worst_ms = 0.0f;
     float *hub32 = nullptr;           // bf16 build: fp32 master rows of the hub columns
     int32_t *dhub_index = nullptr;
+    unsigned long long seg_ticket[64] = {};   // first ticket of each segment of a segmented epoch (source of small async copies)
     std::vector<int32_t> host_hub_index;
     int32_t n_hub = 0;
     std::vector<int32_t> host_key;    // general order: sort key per nonzero (what the kernel stages as `key`)
@@ -1067,6 +1071,7 @@ void fill_params(const ge_glove *h, GloveParams &p, int32_t iteration) {
     p.order_mode = h->cfg.shuffle == GE_SHUFFLE_JAVA ? ORDER_PERM
                  : h->cfg.shuffle == GE_SHUFFLE_DEVICE ? ORDER_BIJECTION : ORDER_IDENTITY;
     p.bA = h->lay.bA; p.bB = h->lay.bB; p.cstart = h->lay.cstart; p.cmeta = h->lay.cmeta; p.n_chunks = h->n_chunks; p.n_hchunks = h->n_hchunks;
+    p.ticket_end = h->n_chunks;
     p.blocked = h->blocked ? 1 : 0; p.hot_enabled = h->cfg.hot_columns != GE_HOT_NONE; p.flush_every = h->flush_every;
     const int64_t domain = h->blocked ? h->n_chunks : h->cfg.nnz;      // what the keyed bijection permutes
     uint32_t bits = 0;
@@ -1718,6 +1723,46 @@ ge_status ge_glove_get_info(ge_glove *h, ge_glove_info *info) {
 
 }  // extern "C"
 namespace ge {
+// A Hogwild epoch in `nseg` launches (ge_sync_epoch: the hub rows of a sharded run are reconciled between them).  The chunks of
+// the epoch are handed out by ticket through a keyed bijection, so tickets [n seg / nseg, n (seg + 1) / nseg) are a random nseg-th
+// of the epoch; the cost accumulates on the device over the segments.  Nothing here blocks the host: glove_epoch_finish does.
+ge_status glove_epoch_segment(ge_glove *h, int32_t iteration, int32_t seg, int32_t nseg) {
+    ge_status st = check_handle(h);
+    if (st != GE_OK) return st;
+    if (h->cfg.mode != GE_MODE_HOGWILD || h->cfg.shuffle == GE_SHUFFLE_JAVA) return ge::fail(GE_ERR_STATE, "a segmented epoch needs a GE_MODE_HOGWILD handle with a device-side order");
+    if (nseg < 1 || nseg > 64 || seg < 0 || seg >= nseg) return ge::fail(GE_ERR_ARG, "segment %d of %d", seg, nseg);
+    GloveParams p;
+    fill_params(h, p, iteration);
+    const int64_t n = h->cfg.nnz > 0 ? h->n_chunks : 0;
+    const int64_t begin = n * seg / nseg, end = n * (seg + 1) / nseg;
+    if (seg == 0) {
+        GE_HIP(hipMemsetAsync(h->dcost, 0, 2 * sizeof(double), h->stream));
+        GE_HIP(hipEventRecord(h->ev0, h->stream));
+        h->last_launches = 0;
+    }
+    if (end > begin) {
+        h->seg_ticket[seg] = (unsigned long long)begin;
+        GE_HIP(hipMemcpyAsync(p.queue, &h->seg_ticket[seg], sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
+        p.ticket_end = end;
+        hipLaunchKernelGGL(h->hw_fn, dim3(h->hw_blocks), dim3(256), 0, h->stream, p, (int32_t)h->hw_workers);
+        ++h->last_launches;
+        GE_HIP(hipGetLastError());
+    }
+    if (seg == nseg - 1) GE_HIP(hipEventRecord(h->ev1, h->stream));
+    return GE_OK;
+}
+ge_status glove_epoch_finish(ge_glove *h, double *cost_sum) {
+    ge_status st = check_handle(h);
+    if (st != GE_OK) return st;
+    double total = 0.0;
+    GE_HIP(hipMemcpyAsync(&total, h->dcost, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    GE_HIP(hipStreamSynchronize(h->stream));
+    GE_HIP(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));      // first launch to last, the exchanges between them included
+    if (cost_sum) *cost_sum = total;
+    return GE_OK;
+}
+// the hub columns of this handle's layout (ascending), for the exchange of a sharded run
+const std::vector<int32_t> *glove_hub_columns(const ge_glove *h) { return h ? &h->lay.hubs : nullptr; }
 // what sync.hip needs to know about a handle (struct ge_glove is private to this file)
 ge_status glove_sync_view(ge_glove *h, int32_t *opt, int32_t *mode, void **stream, int32_t *device) {
     if (!h) return ge::fail(GE_ERR_ARG, "null ge_glove handle");

@@ -163,6 +163,7 @@ ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const 
     out->flush_min = rq.flush_every > 0 ? std::min<int32_t>(rq.flush_every, LAYOUT_CHUNK) : LAYOUT_CHUNK;
     for (int32_t c : hubs) out->flush_min = std::min(out->flush_min, flush_limit(c));
     if (rq.want_hub_index) { out->hub_index = hub_rank; out->n_hub = n_hub; }
+    out->hubs = hubs;
 
     // ---- stable sort: hubs column-major, the rest grouped by row ----
     int32_t *d_rank = nullptr; uint32_t *d_key = nullptr, *d_skey = nullptr; int32_t *d_val = nullptr, *d_sval = nullptr;

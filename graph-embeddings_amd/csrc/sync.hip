@@ -26,12 +26,18 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
 
 // glove.hip
-namespace ge { ge_status glove_sync_view(ge_glove *h, int32_t *opt, int32_t *mode, void **stream, int32_t *device); }
+namespace ge {
+ge_status glove_sync_view(ge_glove *h, int32_t *opt, int32_t *mode, void **stream, int32_t *device);
+ge_status glove_epoch_segment(ge_glove *h, int32_t iteration, int32_t seg, int32_t nseg);
+ge_status glove_epoch_finish(ge_glove *h, double *cost_sum);
+const std::vector<int32_t> *glove_hub_columns(const ge_glove *h);
+}
 
 namespace {
 
@@ -83,63 +89,140 @@ __global__ __launch_bounds__(256) void k_sync_turn(float *__restrict__ table, in
     }
 }
 
-// The same step for the large tables (cols and the table's row stride multiples of 4, sum rule): one wavefront per row, four
-// elements per lane, 128-bit accesses, no division -- 22 bytes per element for land + take on a bf16 wire (read: table 4,
-// base 4, wire 2, own 2; written: table 4, base 4, own 2), HBM streaming.
-template <bool LAND, bool TAKE, bool W16>
-__global__ __launch_bounds__(256) void k_sync_turn_rows4(float *__restrict__ table, int64_t t_stride, int32_t cols4, int64_t rows,
+// The same step for the large tables (cols and the table's row stride multiples of 4, sum rule): 22 bytes per element for land +
+// take on a bf16 wire (read: table 4, base 4, wire 2, own 2; written: table 4, base 4, own 2), HBM streaming.  One thread = one
+// group of four consecutive elements; consecutive threads take consecutive groups of the DENSE buffers, so every wave instruction
+// on base / wire / own covers one contiguous kilobyte (512 bytes on a bf16 buffer) whatever the row length, and all 64 lanes work
+// (a wave per row left 14 of 64 lanes idle at dim 200 and read the dense buffers in 800-byte pieces n_waves rows apart).  The
+// table side follows the records: group q lives in row q / cols4.  U groups per thread are loaded before any is stored.
+// NT: the dense buffers are touched once per exchange and never fit a cache -- nontemporal accesses keep them out of the way of
+// the table's lines.
+template <bool LAND, bool TAKE, bool W16, bool NT>
+__global__ __launch_bounds__(256) void k_sync_turn_flat4(float *__restrict__ table, int64_t t_stride, uint32_t cols4, uint32_t n4,
                                                          float *__restrict__ base, void *__restrict__ wire_, void *__restrict__ own_) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-    constexpr int U = 2;                                                    // rows in flight per wavefront: every load of both before any store
-    for (int64_t r0 = wave; r0 < rows; r0 += U * n_waves) {
-        for (int32_t g = lane; g < cols4; g += 64) {
-            float4 tv[U], cv[U], wf[U], of[U]; uint2 wh[U], oh[U]; bool live[U];
+    constexpr int U = 4;
+    const uint32_t step = gridDim.x * blockDim.x;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    auto ld4 = [](const float4 *p) -> float4 {
+        if constexpr (NT) { const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+        else return *p;
+    };
+    auto ld2 = [](const uint2 *p) -> uint2 {
+        if constexpr (NT) { const v2u v = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(p)); return make_uint2(v.x, v.y); }
+        else return *p;
+    };
+    auto st4 = [](float4 *p, float4 v) {
+        if constexpr (NT) { v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, reinterpret_cast<v4f *>(p)); }
+        else *p = v;
+    };
+    auto st2 = [](uint2 *p, uint2 v) {
+        if constexpr (NT) { v2u w; w.x = v.x; w.y = v.y; __builtin_nontemporal_store(w, reinterpret_cast<v2u *>(p)); }
+        else *p = v;
+    };
+    for (uint32_t q0 = blockIdx.x * blockDim.x + threadIdx.x; q0 < n4; q0 += U * step) {      // n4 < 2^29: vocab * dim < 2^31 (geglove.h)
+        float4 tv[U], cv[U], wf[U], of[U]; uint2 wh[U], oh[U]; float4 *tp[U]; bool live[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t r = r0 + u * n_waves;
-                live[u] = r < rows;
-                if (!live[u]) continue;
-                const int64_t d = r * cols4 + g;                            // index of the group in the dense buffers
-                tv[u] = reinterpret_cast<const float4 *>(table + r * t_stride)[g];
-                cv[u] = reinterpret_cast<const float4 *>(base)[d];
-                if (LAND) {
-                    if (W16) { wh[u] = reinterpret_cast<const uint2 *>(wire_)[d]; oh[u] = reinterpret_cast<const uint2 *>(own_)[d]; }
-                    else { wf[u] = reinterpret_cast<const float4 *>(wire_)[d]; of[u] = reinterpret_cast<const float4 *>(own_)[d]; }
-                }
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + (uint32_t)u * step;
+            live[u] = q < n4 && q >= q0;                                   // (q >= q0: no wrap-around of the 32-bit index)
+            if (!live[u]) continue;
+            const uint32_t r = q / cols4, g = q - r * cols4;
+            tp[u] = reinterpret_cast<float4 *>(table + (int64_t)r * t_stride) + g;
+            tv[u] = *tp[u];
+            cv[u] = ld4(reinterpret_cast<const float4 *>(base) + q);
+            if (LAND) {
+                if (W16) { wh[u] = ld2(reinterpret_cast<const uint2 *>(wire_) + q); oh[u] = ld2(reinterpret_cast<const uint2 *>(own_) + q); }
+                else { wf[u] = ld4(reinterpret_cast<const float4 *>(wire_) + q); of[u] = ld4(reinterpret_cast<const float4 *>(own_) + q); }
             }
+        }
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if (!live[u]) continue;
-                const int64_t r = r0 + u * n_waves, d = r * cols4 + g;
-                float res[4] = {tv[u].x - cv[u].x, tv[u].y - cv[u].y, tv[u].z - cv[u].z, tv[u].w - cv[u].w};
-                if (LAND) {
-                    float w[4], o[4];
-                    if (W16) {
-                        w[0] = bf16_to_f32(wh[u].x & 0xffffu); w[1] = bf16_to_f32(wh[u].x >> 16); w[2] = bf16_to_f32(wh[u].y & 0xffffu); w[3] = bf16_to_f32(wh[u].y >> 16);
-                        o[0] = bf16_to_f32(oh[u].x & 0xffffu); o[1] = bf16_to_f32(oh[u].x >> 16); o[2] = bf16_to_f32(oh[u].y & 0xffffu); o[3] = bf16_to_f32(oh[u].y >> 16);
-                    } else {
-                        w[0] = wf[u].x; w[1] = wf[u].y; w[2] = wf[u].z; w[3] = wf[u].w; o[0] = of[u].x; o[1] = of[u].y; o[2] = of[u].z; o[3] = of[u].w;
-                    }
-                    const float c[4] = {cv[u].x + w[0], cv[u].y + w[1], cv[u].z + w[2], cv[u].w + w[3]};
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            const uint32_t q = q0 + (uint32_t)u * step;
+            float res[4] = {tv[u].x - cv[u].x, tv[u].y - cv[u].y, tv[u].z - cv[u].z, tv[u].w - cv[u].w};
+            if (LAND) {
+                float w[4], o[4];
+                if (W16) {
+                    w[0] = bf16_to_f32(wh[u].x & 0xffffu); w[1] = bf16_to_f32(wh[u].x >> 16); w[2] = bf16_to_f32(wh[u].y & 0xffffu); w[3] = bf16_to_f32(wh[u].y >> 16);
+                    o[0] = bf16_to_f32(oh[u].x & 0xffffu); o[1] = bf16_to_f32(oh[u].x >> 16); o[2] = bf16_to_f32(oh[u].y & 0xffffu); o[3] = bf16_to_f32(oh[u].y >> 16);
+                } else {
+                    w[0] = wf[u].x; w[1] = wf[u].y; w[2] = wf[u].z; w[3] = wf[u].w; o[0] = of[u].x; o[1] = of[u].y; o[2] = of[u].z; o[3] = of[u].w;
+                }
+                const float c[4] = {cv[u].x + w[0], cv[u].y + w[1], cv[u].z + w[2], cv[u].w + w[3]};
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) res[k] -= o[k];
-                    reinterpret_cast<float4 *>(table + r * t_stride)[g] = make_float4(c[0] + res[0], c[1] + res[1], c[2] + res[2], c[3] + res[3]);
-                    reinterpret_cast<float4 *>(base)[d] = make_float4(c[0], c[1], c[2], c[3]);
-                }
-                if (TAKE) {
-                    if (W16) {
-                        const uint32_t h0 = f32_to_bf16_rne(res[0]), h1 = f32_to_bf16_rne(res[1]), h2 = f32_to_bf16_rne(res[2]), h3 = f32_to_bf16_rne(res[3]);
-                        const uint2 hv = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-                        reinterpret_cast<uint2 *>(own_)[d] = hv;
-                    } else {
-                        const float4 rv = make_float4(res[0], res[1], res[2], res[3]);
-                        reinterpret_cast<float4 *>(own_)[d] = rv;
-                    }
-                }
+                for (int k = 0; k < 4; ++k) res[k] -= o[k];
+                *tp[u] = make_float4(c[0] + res[0], c[1] + res[1], c[2] + res[2], c[3] + res[3]);
+                st4(reinterpret_cast<float4 *>(base) + q, make_float4(c[0], c[1], c[2], c[3]));
+            }
+            if (TAKE) {
+                if (W16) {
+                    const uint32_t h0 = f32_to_bf16_rne(res[0]), h1 = f32_to_bf16_rne(res[1]), h2 = f32_to_bf16_rne(res[2]), h3 = f32_to_bf16_rne(res[3]);
+                    st2(reinterpret_cast<uint2 *>(own_) + q, make_uint2(h0 | (h1 << 16), h2 | (h3 << 16)));
+                } else st4(reinterpret_cast<float4 *>(own_) + q, make_float4(res[0], res[1], res[2], res[3]));
             }
         }
     }
+}
+
+// ---- hub rows, reconciled between the segments of an epoch (ge_sync_epoch) ----------------------------------------------------
+// The busiest context rows receive thousands of updates per rank and epoch.  Early in training they grow multiplicatively, and
+// eight ranks that each multiply a row by 2.6 from the same start sum to a factor 14: with one exchange per epoch the sharded run
+// overshoots where the single-GPU run settles, and its accumulators -- fed by gradients that were small while it lagged -- never
+// catch up (measured with eight ranks on one GPU: DESIGN.md 7).  Inside one GPU the same rows are kept together by publishing
+// deltas every m_j updates; across GPUs they are kept together by exchanging them S times per epoch: they are few (the union of
+// the ranks' hub columns: a few thousand rows, megabytes), so each such exchange is one small fp32 all-reduce.
+// One wavefront per hub row.  buf = [rows H x D | accumulator rows H x D | gradSqCBias H | cBias H | count H].
+// take: buf = table - base (fp32, exact: nothing of these rows is ever in flight in the large exchange, whose take sees 0 for them)
+__global__ __launch_bounds__(256) void k_hub_take(const int32_t *__restrict__ list, int32_t H, int32_t D,
+                                                  const float *__restrict__ rows, int64_t rows_stride, const float *__restrict__ rows_base,
+                                                  const float *__restrict__ acc, int64_t acc_stride, const float *__restrict__ acc_base,
+                                                  const float *__restrict__ accb, int64_t accb_stride, const float *__restrict__ accb_base,
+                                                  const float *__restrict__ bias, int64_t bias_stride, const float *__restrict__ bias_base,
+                                                  float *__restrict__ buf) {
+    const int lane = threadIdx.x & 63;
+    const int32_t h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= H) return;
+    const int64_t v = list[h];
+    float *const b_rows = buf, *const b_acc = buf + (int64_t)H * D, *const b_accb = b_acc + (int64_t)H * D, *const b_bias = b_accb + H, *const b_cnt = b_bias + H;
+    for (int32_t d = lane; d < D; d += 64) {
+        b_rows[(int64_t)h * D + d] = rows[v * rows_stride + d] - rows_base[v * D + d];
+        b_acc[(int64_t)h * D + d] = acc[v * acc_stride + d] - acc_base[v * D + d];
+    }
+    if (lane == 0) {
+        b_accb[h] = accb[v * accb_stride] - accb_base[v];
+        const float db = bias[v * bias_stride] - bias_base[v];
+        b_bias[h] = db; b_cnt[h] = db != 0.0f ? 1.0f : 0.0f;
+    }
+}
+// land: base += the summed deltas (cBias: the mean over the ranks that moved it); table = base -- every rank's hub rows ARE the consensus
+__global__ __launch_bounds__(256) void k_hub_land(const int32_t *__restrict__ list, int32_t H, int32_t D,
+                                                  float *__restrict__ rows, int64_t rows_stride, float *__restrict__ rows_base,
+                                                  float *__restrict__ acc, int64_t acc_stride, float *__restrict__ acc_base,
+                                                  float *__restrict__ accb, int64_t accb_stride, float *__restrict__ accb_base,
+                                                  float *__restrict__ bias, int64_t bias_stride, float *__restrict__ bias_base,
+                                                  const float *__restrict__ buf) {
+    const int lane = threadIdx.x & 63;
+    const int32_t h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= H) return;
+    const int64_t v = list[h];
+    const float *const b_rows = buf, *const b_acc = buf + (int64_t)H * D, *const b_accb = b_acc + (int64_t)H * D, *const b_bias = b_accb + H, *const b_cnt = b_bias + H;
+    for (int32_t d = lane; d < D; d += 64) {
+        const float c = rows_base[v * D + d] + b_rows[(int64_t)h * D + d];
+        rows_base[v * D + d] = c; rows[v * rows_stride + d] = c;
+        const float a = acc_base[v * D + d] + b_acc[(int64_t)h * D + d];
+        acc_base[v * D + d] = a; acc[v * acc_stride + d] = a;
+    }
+    if (lane == 0) {
+        const float a = accb_base[v] + b_accb[h];
+        accb_base[v] = a; accb[v * accb_stride] = a;
+        const float c = bias_base[v] + b_bias[h] / fmaxf(b_cnt[h], 1.0f);
+        bias_base[v] = c; bias[v * bias_stride] = c;
+    }
+}
+__global__ void k_mark(const int32_t *list, int32_t n, float *flags) {
+    const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) flags[list[k]] = 1.0f;
 }
 
 // dense <-> strided copies (base initialisation, replicate)
@@ -169,6 +252,7 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t *, ncclConfig_t *) = nullptr;      // optional (a second communicator for the hub rows)
     bool ok = false;
 };
 Rccl &rccl() {
@@ -187,6 +271,7 @@ Rccl &rccl() {
         r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
         r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        r.CommSplit = (decltype(r.CommSplit))dlsym(r.lib, "ncclCommSplit");
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.Broadcast && r.GetErrorString;
     });
     return r;
@@ -235,11 +320,17 @@ struct ge_sync {
     hipStream_t main = nullptr;     // the handle's stream: take / land kernels are ordered with its epochs
     hipStream_t side = nullptr;     // RCCL's stream: the all-reduce runs beside the next epoch
     hipEvent_t ev_taken = nullptr, ev_reduced = nullptr;
+    ncclComm_t hub_comm = nullptr;  // the hub rows' small all-reduces: a communicator and a stream of their own, so that they need not
+    hipStream_t hub_side = nullptr; // queue behind the large all-reduce that runs under the epoch (ncclCommSplit; else the same pair)
+    hipEvent_t ev_hub_a = nullptr, ev_hub_b = nullptr;
     int device = 0, cus = 256;
     std::vector<Entry> ent;
     std::vector<void *> owned;
     int64_t calls = 0;
     uint32_t seed = 0x5EED;
+    int32_t *hub_list = nullptr; int32_t n_hub = 0;       // the union of the ranks' hub columns (ascending), on the device
+    float *hub_buf = nullptr;                              // [n_hub x (2 D + 3)] fp32: the hub rows' deltas of one small exchange
+    void *hub_ticket = nullptr;
     ge_context_layout lay{};
     template <typename T> hipError_t alloc(T **out, size_t n) {
         hipError_t e = hipMalloc((void **)out, sizeof(T) * std::max<size_t>(n, 1));
@@ -299,12 +390,16 @@ ge_status launch_turn(ge_sync *s, Entry &e, bool land, bool take) {
         return ge_exchange_turn_bf16((uint16_t *)s->lay.table, s->lay.row_stride, s->lay.hub_rows, s->lay.hub_index, s->lay.vocab_size, s->lay.dim, e.base,
                                      (uint16_t *)e.wire, (uint16_t *)e.own, land, take, s->seed ^ ((uint32_t)s->cfg.rank * 0x9E3779B1u), s->main);
     }
-    if (!e.mean && e.cols % 4 == 0 && e.t_stride % 4 == 0 && ((uintptr_t)e.table % 16) == 0) {       // the large tables
-        const dim3 g4((unsigned)std::max<int64_t>(1, std::min<int64_t>((e.rows + 3) / 4, (int64_t)s->cus * 16))), b4(256);
+    if (!e.mean && e.cols % 4 == 0 && e.t_stride % 4 == 0 && ((uintptr_t)e.table % 16) == 0 && e.n / 4 < ((int64_t)1 << 31)) {       // the large tables
+        const int64_t n4 = e.n / 4;
+        const dim3 g4((unsigned)std::max<int64_t>(1, std::min<int64_t>((n4 + 1023) / 1024, (int64_t)s->cus * 8))), b4(256);
+        static const bool nt = [] { const char *v = std::getenv("GE_SYNC_NT"); return v ? std::atoi(v) != 0 : true; }();
 #define GE_TURN4(L, T)                                                                                                              \
         do {                                                                                                                        \
-            if (e.w16) hipLaunchKernelGGL((k_sync_turn_rows4<L, T, true>), g4, b4, 0, s->main, e.table, e.t_stride, e.cols / 4, e.rows, e.base, e.wire, e.own); \
-            else hipLaunchKernelGGL((k_sync_turn_rows4<L, T, false>), g4, b4, 0, s->main, e.table, e.t_stride, e.cols / 4, e.rows, e.base, e.wire, e.own); \
+            if (e.w16 && nt) hipLaunchKernelGGL((k_sync_turn_flat4<L, T, true, true>), g4, b4, 0, s->main, e.table, e.t_stride, (uint32_t)(e.cols / 4), (uint32_t)n4, e.base, e.wire, e.own); \
+            else if (e.w16) hipLaunchKernelGGL((k_sync_turn_flat4<L, T, true, false>), g4, b4, 0, s->main, e.table, e.t_stride, (uint32_t)(e.cols / 4), (uint32_t)n4, e.base, e.wire, e.own); \
+            else if (nt) hipLaunchKernelGGL((k_sync_turn_flat4<L, T, false, true>), g4, b4, 0, s->main, e.table, e.t_stride, (uint32_t)(e.cols / 4), (uint32_t)n4, e.base, e.wire, e.own); \
+            else hipLaunchKernelGGL((k_sync_turn_flat4<L, T, false, false>), g4, b4, 0, s->main, e.table, e.t_stride, (uint32_t)(e.cols / 4), (uint32_t)n4, e.base, e.wire, e.own); \
         } while (0)
         if (land && take) GE_TURN4(true, true); else if (land) GE_TURN4(true, false); else GE_TURN4(false, true);
 #undef GE_TURN4
@@ -369,6 +464,44 @@ ge_status wait_reduce(ge_sync *s) {
         if (st == GE_OK && e.mean) st = s->tr.wait(s->tr.user, e.ticket_cnt);
         if (st != GE_OK) return ge::fail(st, "transport.wait failed for %s", e.name);
     }
+    return GE_OK;
+}
+
+// sum of a small fp32 device buffer over the ranks, ordered on the handle's stream (RCCL: asynchronous, on the hub stream)
+ge_status allreduce_f32_small(ge_sync *s, float *dbuf, int64_t n) {
+    if (s->loop) {
+        GE_HIP(hipStreamSynchronize(s->main));
+        return local_allreduce(s->loop, s->cfg.rank, dbuf, n, GE_DTYPE_F32, false, 0);
+    }
+    if (s->tr.start) {
+        GE_HIP(hipStreamSynchronize(s->main));
+        void *t = nullptr;
+        ge_status st = s->tr.start(s->tr.user, dbuf, n, GE_DTYPE_F32, &t);
+        if (st == GE_OK) st = s->tr.wait(s->tr.user, t);
+        return st == GE_OK ? GE_OK : ge::fail(st, "transport failed for the hub rows");
+    }
+    GE_HIP(hipEventRecord(s->ev_hub_a, s->main));
+    GE_HIP(hipStreamWaitEvent(s->hub_side, s->ev_hub_a, 0));
+    GE_NCCL(rccl().AllReduce(dbuf, dbuf, (size_t)n, ncclFloat32, ncclSum, s->hub_comm, s->hub_side));
+    GE_HIP(hipEventRecord(s->ev_hub_b, s->hub_side));
+    GE_HIP(hipStreamWaitEvent(s->main, s->ev_hub_b, 0));
+    return GE_OK;
+}
+
+// one small exchange of the hub rows (rows, accumulator rows, both scalars): take, all-reduce, land; exact replicas of these rows after it
+ge_status hub_exchange(ge_sync *s) {
+    if (s->n_hub == 0) return GE_OK;
+    const Entry &er = s->ent[0], &eb = s->ent[1], &ea = s->ent[2], &eab = s->ent[3];
+    const int32_t H = s->n_hub, D = s->lay.dim;
+    const dim3 g((unsigned)((H + 3) / 4)), b(256);
+    hipLaunchKernelGGL(k_hub_take, g, b, 0, s->main, s->hub_list, H, D, er.table, er.t_stride, er.base, ea.table, ea.t_stride, ea.base,
+                       eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf);
+    GE_HIP(hipGetLastError());
+    ge_status st = allreduce_f32_small(s, s->hub_buf, (int64_t)H * (2 * D + 3));
+    if (st != GE_OK) return st;
+    hipLaunchKernelGGL(k_hub_land, g, b, 0, s->main, s->hub_list, H, D, er.table, er.t_stride, er.base, ea.table, ea.t_stride, ea.base,
+                       eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf);
+    GE_HIP(hipGetLastError());
     return GE_OK;
 }
 
@@ -454,7 +587,12 @@ void ge_sync_destroy(ge_sync *s) {
     (void)hipSetDevice(s->device);
     if (s->main) (void)hipStreamSynchronize(s->main);
     if (s->side) (void)hipStreamSynchronize(s->side);
+    if (s->hub_side) (void)hipStreamSynchronize(s->hub_side);
+    if (s->hub_comm && s->hub_comm != s->comm && rccl().ok) (void)rccl().CommDestroy(s->hub_comm);
     if (s->comm && rccl().ok) (void)rccl().CommDestroy(s->comm);
+    if (s->ev_hub_a) (void)hipEventDestroy(s->ev_hub_a);
+    if (s->ev_hub_b) (void)hipEventDestroy(s->ev_hub_b);
+    if (s->hub_side) (void)hipStreamDestroy(s->hub_side);
     for (void *q : s->owned) (void)hipFree(q);
     if (s->ev_taken) (void)hipEventDestroy(s->ev_taken);
     if (s->ev_reduced) (void)hipEventDestroy(s->ev_reduced);
@@ -525,6 +663,44 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
             ncclUniqueId id; std::memcpy(&id, cfg->rccl_id, sizeof(id));
             ncclResult_t r = rccl().CommInitRank(&s->comm, cfg->world, id, cfg->rank);
             if (r != ncclSuccess) { ge_status e2 = ge::fail(GE_ERR_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString(r)); s->comm = nullptr; ge_sync_destroy(s); return e2; }
+            GE_TRYS(hipStreamCreateWithFlags(&s->hub_side, hipStreamNonBlocking));
+            GE_TRYS(hipEventCreateWithFlags(&s->ev_hub_a, hipEventDisableTiming));
+            GE_TRYS(hipEventCreateWithFlags(&s->ev_hub_b, hipEventDisableTiming));
+            s->hub_comm = s->comm;
+            if (rccl().CommSplit) {
+                ncclComm_t c2 = nullptr;
+                if (rccl().CommSplit(s->comm, 0, cfg->rank, &c2, nullptr) == ncclSuccess && c2) s->hub_comm = c2;
+            }
+        }
+        // The hub rows of the small exchanges (ge_sync_epoch): the union of the ranks' hub columns (every rank flags its own in a
+        // [V] vector, the vector is summed).  fp32 rows only: a bf16 handle keeps the fp32 masters of ITS hubs, and a column that is a
+        // hub on one rank and an ordinary bf16 row on another has no common exact representation -- such handles exchange once per epoch.
+        if (s->lay.dtype != GE_DTYPE_BF16) {
+            const std::vector<int32_t> *mine = ge::glove_hub_columns(h);
+            float *flags = nullptr; int32_t *tmp = nullptr;
+            GE_TRYS(hipMalloc((void **)&flags, sizeof(float) * (size_t)std::max<int64_t>(V, 1)));
+            s->owned.push_back(flags);
+            GE_TRYS(hipMemsetAsync(flags, 0, sizeof(float) * (size_t)V, s->main));
+            const int32_t nm = mine ? (int32_t)mine->size() : 0;
+            if (nm > 0) {
+                GE_TRYS(hipMalloc((void **)&tmp, sizeof(int32_t) * (size_t)nm));
+                s->owned.push_back(tmp);
+                GE_TRYS(hipMemcpyAsync(tmp, mine->data(), sizeof(int32_t) * (size_t)nm, hipMemcpyHostToDevice, s->main));
+                hipLaunchKernelGGL(k_mark, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s->main, (const int32_t *)tmp, nm, flags);
+            }
+            st = allreduce_f32_small(s, flags, V);
+            if (st != GE_OK) { ge_sync_destroy(s); return st; }
+            std::vector<float> hf((size_t)V);
+            GE_TRYS(hipMemcpyAsync(hf.data(), flags, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s->main));
+            GE_TRYS(hipStreamSynchronize(s->main));
+            std::vector<int32_t> all;
+            for (int64_t v = 0; v < V; ++v) if (hf[(size_t)v] > 0.0f) all.push_back((int32_t)v);
+            s->n_hub = (int32_t)all.size();
+            if (s->n_hub > 0) {
+                GE_TRYS(s->alloc(&s->hub_list, (size_t)s->n_hub));
+                GE_TRYS(hipMemcpy(s->hub_list, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice));
+                GE_TRYS(s->alloc(&s->hub_buf, (size_t)s->n_hub * (size_t)(2 * D + 3)));
+            }
         }
     }
 #undef GE_TRYS
@@ -544,6 +720,24 @@ ge_status ge_sync_sync(ge_sync *s) {          // lands what an earlier turn left
     ge_status st = ge_sync_turn(s);
     return st == GE_OK ? ge_sync_finish(s) : st;
 }
+
+// One epoch of a sharded run: the handle's epoch in `segments` launches with a small exchange of the hub rows behind each (see
+// k_hub_take).  segments <= 0: twice the number of ranks, at least 8.  The large exchange (ge_sync_turn / ge_sync_sync) follows as
+// before and finds nothing to do for the hub rows.  world == 1, or no hub rows: ge_glove_epoch.
+static ge_status ge_sync_epoch_impl(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum) {
+    if (!s) return ge::fail(GE_ERR_ARG, "null ge_sync handle");
+    if (s->cfg.world == 1 || s->n_hub == 0) return ge_glove_epoch(s->h, iteration, cost_sum);
+    GE_HIP(hipSetDevice(s->device));
+    const int32_t S = std::min(64, segments > 0 ? segments : std::max(8, 2 * s->cfg.world));
+    for (int32_t seg = 0; seg < S; ++seg) {
+        ge_status st = ge::glove_epoch_segment(s->h, iteration, seg, S);
+        if (st == GE_OK) st = hub_exchange(s);
+        if (st != GE_OK) return st;
+    }
+    return ge::glove_epoch_finish(s->h, cost_sum);
+}
+static ge_status epoch_guarded(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum) { GE_GUARD(ge_sync_epoch_impl(s, iteration, segments, cost_sum)); }
+ge_status ge_sync_epoch(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum) { return with_abort(s, epoch_guarded(s, iteration, segments, cost_sum)); }
 
 static ge_status ge_sync_replicate_impl(ge_sync *s, int32_t src) {
     if (!s) return ge::fail(GE_ERR_ARG, "null ge_sync handle");

@@ -161,6 +161,13 @@ class ContextSync:
             cfg.rccl_id = C.cast(self._keep, C.c_void_p)
         capi.check(capi.lib().ge_sync_create(optimizer._h, C.byref(cfg), C.byref(self._h)))
 
+    def epoch(self, iteration=0, segments=0):
+        """One epoch of this rank's handle with the hub rows reconciled `segments` times on the way (ge_sync_epoch; every rank calls
+        it).  Returns the rank's cost sum, like Adagrad.epoch."""
+        c = C.c_double(0.0)
+        capi.check(capi.lib().ge_sync_epoch(self._h, int(iteration), int(segments), C.byref(c)))
+        return c.value
+
     def begin(self, everything=False): capi.check(capi.lib().ge_sync_begin(self._h, int(bool(everything))))
     def finish(self): capi.check(capi.lib().ge_sync_finish(self._h))
     def turn(self): capi.check(capi.lib().ge_sync_turn(self._h))

@@ -255,7 +255,7 @@ struct Configuration {
              double hot_theta = 0, stale_budget = 0; int flush_every = 0, blocks_per_cu = 0, layout_flags = 0;
              long long bca_table_slots = 0, bca_pool_entries = 0;
              // multi-GPU: gpus ranks, one thread each, rows sharded, context exchanged through ge_sync
-             int gpus = 1, accum_every = 0; std::string exchange = "overlap", transport = "auto", wire = "bf16"; } device;
+             int gpus = 1, accum_every = 0, hub_segments = 0; std::string exchange = "overlap", transport = "auto", wire = "bf16"; } device;
     std::vector<std::string> ignored_keys;     // legacy keys of the shipped YAMLs that the bean does not know
 
     int getThreads() const {       // Configuration.java:71-73
@@ -347,6 +347,7 @@ struct Configuration {
                     else if (q.first == "transport") c.device.transport = q.second.scalar;      // auto | rccl | host
                     else if (q.first == "wire") c.device.wire = q.second.scalar;                // bf16 | f32
                     else if (q.first == "accum_every") c.device.accum_every = (int)num(&q.second);
+                    else if (q.first == "hub_segments") c.device.hub_segments = (int)num(&q.second);
                     else if (q.first == "hot_theta") c.device.hot_theta = num(&q.second);
                     else if (q.first == "stale_budget") c.device.stale_budget = num(&q.second);
                     else if (q.first == "flush_every") c.device.flush_every = (int)num(&q.second);
@@ -1021,7 +1022,7 @@ public:
             std::unique_ptr<ge_sync, void (*)(ge_sync *)> sg(sy, ge_sync_destroy);
             for (int iteration = 0; iteration < config_.opt.maxiter; ++iteration) {
                 double c = 0;
-                check(ge_glove_epoch(h, iteration, &c));
+                check(ge_sync_epoch(sy, iteration, config_.device.hub_segments, &c));     // the epoch, hub rows reconciled on the way
                 check(overlap ? ge_sync_turn(sy) : ge_sync_sync(sy));
                 cost[(size_t)r] = c;
                 bar.wait();

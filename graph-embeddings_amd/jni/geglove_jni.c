@@ -127,6 +127,14 @@ JNIEXPORT void JNICALL Java_org_uu_nl_embedding_hip_Native_localGroupAbort(JNIEn
     (void)env; (void)cls;
     ge_local_group_abort((ge_local_group *)(intptr_t)group);
 }
+/* double syncEpoch(long sync, int iteration, int segments): the rank's epoch with the hub rows reconciled on the way (ge_sync_epoch) */
+JNIEXPORT jdouble JNICALL Java_org_uu_nl_embedding_hip_Native_syncEpoch(JNIEnv *env, jclass cls, jlong sync, jint iteration, jint segments) {
+    (void)cls;
+    double cost = 0;
+    ge_status st = ge_sync_epoch((ge_sync *)(intptr_t)sync, iteration, segments, &cost);
+    if (st != GE_OK) { throw_ge(env, st); return 0; }
+    return cost;
+}
 /* long syncCreate(long glove, int world, int rank, int wire, int accumEvery, byte[] rcclId (or null), long localGroup (or 0)) */
 JNIEXPORT jlong JNICALL Java_org_uu_nl_embedding_hip_Native_syncCreate(
         JNIEnv *env, jclass cls, jlong glove, jint world, jint rank, jint wire, jint accumEvery, jbyteArray rcclId, jlong localGroup) {

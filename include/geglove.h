@@ -442,6 +442,15 @@ ge_status ge_sync_begin(ge_sync *s, int32_t everything);
 ge_status ge_sync_finish(ge_sync *s);
 ge_status ge_sync_turn(ge_sync *s);
 ge_status ge_sync_sync(ge_sync *s);
+/* One epoch of a sharded run, to be called INSTEAD of ge_glove_epoch by every rank (collective): the handle's epoch runs in
+ * `segments` launches (<= 0: twice the number of ranks, at least 8; at most 64) and behind each one the HUB rows of the context side
+ * -- the union of the ranks' hub columns, a few thousand rows -- are reconciled exactly in one small fp32 all-reduce (rows and both
+ * accumulators summed, cBias averaged over the ranks that moved it).  Without it eight ranks that each push a busy row for a whole
+ * epoch from the same start overshoot where one GPU settles (measured: DESIGN.md 7); inside a GPU the same rows are held together by
+ * publishing deltas every few updates, across GPUs by this.  ge_sync_turn / ge_sync_sync follow as before (they find nothing left to
+ * do for the hub rows).  *cost_sum as ge_glove_epoch.  fp32 rows; a bf16 handle (whose hub rows have per-rank fp32 masters), a
+ * one-rank run and a run without hub columns get one plain ge_glove_epoch. */
+ge_status ge_sync_epoch(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum);
 /* Ends a run: lands what is in flight, exchanges everything not sent yet, then every rank takes rank src's fp32 tables. */
 ge_status ge_sync_replicate(ge_sync *s, int32_t src);
 /* n host doubles summed (op 0) or maximised (op 1) over the ranks through RCCL: the epoch's cost (Optimizer.java:94-96 needs

@@ -186,9 +186,11 @@ def _java_rows(seed, D, rows, bf16=False):
     return out
 
 
-@pytest.mark.parametrize("D,dtype", [(200, "f32"), (300, "bf16")])
-def test_c4_c5_vocabulary_on_one_gpu(gpu, D, dtype):
-    V = 5_000_000
+@pytest.mark.parametrize("D,dtype,V", [(200, "f32", 5_200_000), (300, "bf16", 5_000_000)])
+def test_c4_c5_vocabulary_on_one_gpu(gpu, D, dtype, V):
+    """fp32 rows: C4's own V = 5 M gives 5 M x 416 = 2.08e9 floats per record table, just UNDER 2^31 elements (its byte offsets
+    pass 2^32 at row 2.58 M); V = 5.2 M (2.16e9 floats, still V * D < 2^31 as the Java arrays need) puts element offsets past
+    2^31 as well.  bf16 rows at C5's V = 5 M: 4.64e9 bf16 elements per record table."""
     rng = np.random.default_rng(3)
     # a hub-heavy matrix over the WHOLE id range (rows and columns up to V - 1) + a conflict-free batch to count visits with
     n_cf = 200_000
@@ -198,9 +200,9 @@ def test_c4_c5_vocabulary_on_one_gpu(gpu, D, dtype):
     cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, dtype=dtype)
     opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
     info = opt.info()
-    assert (V * info["row_stride"] > 2 ** 31) if dtype == "f32" else (V * info["row_stride"] * 2 > 2 ** 31)      # the point of the test
+    assert V * info["row_stride"] > 2 ** 31 and V * D < 2 ** 31                                          # the point of the test
     # 1. the Java draw order on rows across the whole table, the last one included
-    rows = sorted(set([0, 1, 2_581_110, 2_581_111, V // 2, V - 2, V - 1] + rng.integers(0, V, 12).tolist()))
+    rows = sorted(set([0, 1, 2_581_110, 2_581_111, 5_162_220, 5_162_221, V // 2, V - 2, V - 1][:9 if V > 5_162_221 else 4] + [V // 2, V - 2, V - 1] + rng.integers(0, V, 12).tolist()))
     want = _java_rows(42, D, rows, bf16=dtype == "bf16")
     foc = opt.get_state("focus").reshape(V, D); ctx = opt.get_state("context").reshape(V, D)
     fb, cb = opt.get_state("fbias"), opt.get_state("cbias")

@@ -292,7 +292,7 @@ def _oracle8():
     return _ORACLE8["ref"]
 
 
-def _run_rank_threads(world, V, N, D, epochs, exchange, wire, dtype="f32", lazy_every=2, fail_rank=None):
+def _run_rank_threads(world, V, N, D, epochs, exchange, wire, dtype="f32", lazy_every=2, fail_rank=None, hub_segments=None):
     """One thread per rank; every rank owns a ge_glove handle (its block of focus rows) on device 0 and a ge_sync of the group."""
     import threading
     import geglove
@@ -309,15 +309,16 @@ def _run_rank_threads(world, V, N, D, epochs, exchange, wire, dtype="f32", lazy_
         try:
             rows = parallel.shard_rows(V, world, r)
             si, sj, sx = parallel.shard_nonzeros(I, J, X, rows)
-            cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, row_range=rows, dtype=dtype,
-                              workers=-256 if exchange == "overlap" else 0)
+            # (library-default workers in both forms: the slots a real run reserves for RCCL's kernels, workers = -256, would leave a
+            # matrix this small four workers and -- the hub set being relative to the worker count -- no hub columns at all)
+            cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, row_range=rows, dtype=dtype)
             opt = geglove.Adagrad(geglove.CooMatrix(V, si, sj, sx, xmax), cfg, cfg.costFunction())
             bar.wait(timeout=600)
             sync = parallel.ContextSync(opt, world, r, wire=wire, accum_every=lazy_every, local_group=grp)
             for it in range(epochs):
                 if fail_rank == r and it == 1:
                     raise RuntimeError("rank %d leaves" % r)
-                cost[it, r] = opt.epoch(it)
+                cost[it, r] = sync.epoch(it) if hub_segments is None else (sync.epoch(it, hub_segments) if hub_segments > 0 else opt.epoch(it))
                 sync.turn() if exchange == "overlap" else sync.sync()
             sync.replicate()
             out[r] = {k: opt.get_state(k) for k in CTX}
@@ -349,11 +350,24 @@ def test_eight_ranks_share_one_gpu(gpu, exchange):
     ref = _oracle8()
     ratio = np.array(costs) / np.array(ref)
     print("eight ranks %s D=%d: cost / oracle %s" % (exchange, W8["D"], np.round(ratio, 3).tolist()))
-    assert np.all(np.isfinite(costs)) and np.all(np.diff(costs) < 0)
+    assert np.all(np.isfinite(costs)) and costs[-1] < costs[2] < costs[0]
     # bands: the blocked order and eight shards shift the first two epochs; from the third the sharded run tracks the
     # single-process oracle (synchronous: every rank sees the others' moves after each step; overlapped: one step late)
     np.testing.assert_allclose(costs[:2], ref[:2], rtol=0.25)
     np.testing.assert_allclose(costs[2:], ref[2:], rtol=0.06 if exchange == "sync" else 0.10)
+
+
+def test_eight_ranks_need_the_hub_rows_reconciled_inside_the_epoch(gpu):
+    """What ge_sync_epoch is for: the same eight-rank run with ONE exchange per epoch for every row (ge_glove_epoch + ge_sync_sync)
+    overshoots on the busiest context rows -- eight ranks each push them for a whole epoch from the same start, the pushes add up --
+    and leaves the oracle's trajectory within a few epochs (measured: NaN in epoch 7; the CPU simulation of the merge rule shows the
+    same, tests/tools/multirank_sim.py), while with the hub rows reconciled between the segments of the epoch it follows it."""
+    costs, out, err, alive = _run_rank_threads(W8["world"], W8["V"], W8["N"], W8["D"], W8["epochs"], "sync", "bf16", hub_segments=0)
+    assert not any(alive) and all(e is None for e in err), err
+    ref = _oracle8()
+    ratio = np.array(costs) / np.array(ref)
+    print("eight ranks, one exchange per epoch for every row: cost / oracle %s" % np.round(ratio, 3).tolist())
+    assert not np.all(np.isfinite(costs)) or ratio[-1] > 1.15
 
 
 def test_a_failing_rank_releases_its_local_group(gpu):

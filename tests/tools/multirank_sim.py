@@ -28,14 +28,18 @@ def bf16(a):
     return u.astype(np.uint32).view(np.float32).reshape(a.shape)
 
 
-def model_cost(I, J, X, xmax, focus, context, fb, cb):
+def model_cost(I, J, X, xmax, focus, context, fb, cb, block=200_000):
     """GloVe cost of a fixed model over all nonzeros (GloveCost.java:9-20 without the update), mean per nonzero."""
-    inner = np.einsum("nd,nd->n", focus[I].astype(np.float64), context[J].astype(np.float64)) + fb[I] + cb[J] - np.log(X.astype(np.float64))
-    w = np.minimum(1.0, (X.astype(np.float64) / xmax) ** 0.75)
-    return float(np.mean(0.5 * w * inner * inner))
+    tot = 0.0
+    for a in range(0, len(I), block):
+        i, j, x = I[a:a + block], J[a:a + block], X[a:a + block].astype(np.float64)
+        inner = np.einsum("nd,nd->n", focus[i].astype(np.float64), context[j].astype(np.float64)) + fb[i] + cb[j] - np.log(x)
+        w = np.minimum(1.0, (x / xmax) ** 0.75)
+        tot += float(np.sum(0.5 * w * inner * inner))
+    return tot / len(I)
 
 
-def run(V, N, D, W, epochs, delay, wire, seed=13):
+def run(V, N, D, W, epochs, delay, wire, seed=13, inflate=False, accum_every=1, hub_segments=0, hub_workers=180):
     I, J, X, xmax = synth.synthetic_coo(V, N, seed=seed)
     N = len(I)                                             # duplicates are merged by the generator
     single = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
@@ -58,19 +62,54 @@ def run(V, N, D, W, epochs, delay, wire, seed=13):
     narrow = bf16 if wire == "bf16" else (lambda a: a)
     for e in range(epochs):
         tot = 0.0
-        for r in range(W):
+        if hub_segments:
+            # ge_sync_epoch: every rank's pass in S segments; behind each, the HUB rows (union of the ranks' hub columns: count on a
+            # rank >= 0.25 N_rank / workers) are reconciled exactly -- rows and accumulators summed, cBias averaged over its movers
+            if e == 0:
+                hub = np.zeros(V, bool)
+                for r in range(W):
+                    c = np.bincount(shards[r][1], minlength=V)
+                    hub |= c >= max(1, int(0.25 * len(shards[r][0]) / hub_workers))
+                hubs = np.nonzero(hub)[0]
+                print("hub rows: %d of %d columns, %.1f %% of the nonzeros" % (len(hubs), V, 100.0 * hub[J].mean()), flush=True)
+            perms = [rngs[r].permutation(len(shards[r][0])) for r in range(W)]
+            for sgm in range(hub_segments):
+                for r in range(W):
+                    si, sj, sx = shards[r]
+                    p = perms[r][len(si) * sgm // hub_segments:len(si) * (sgm + 1) // hub_segments]
+                    tot += float(O.adagrad_job(D, si[p], sj[p], sx[p], xmax, O.COST_GLOVE, st[r]))
+                for k in SUMS + MEANS:
+                    cur = [st[r][k].reshape(V, -1)[hubs] for r in range(W)]
+                    b0 = base[0][k].reshape(V, -1)[hubs]
+                    d = [c - b0 for c in cur]
+                    tsum = sum(d)
+                    if k in MEANS:
+                        tsum = tsum / np.maximum(sum((x != 0).astype(np.float32) for x in d), 1.0)
+                    new = b0 + tsum
+                    for r in range(W):
+                        st[r][k].reshape(V, -1)[hubs] = new
+                        base[r][k].reshape(V, -1)[hubs] = new
+        else:
+          for r in range(W):
             si, sj, sx = shards[r]
             p = rngs[r].permutation(len(si))
-            tot += float(O.adagrad_job(D, si[p], sj[p], sx[p], xmax, O.COST_GLOVE, st[r]))
+            tot += float(O.adagrad_job(D, si[p], sj[p], sx[p], xmax, O.COST_GLOVE, st[r], ctx_acc_scale=float(W) if inflate else None))
         # snapshot this epoch's deltas
         own = [{k: (narrow(st[r][k] - base[r][k]) if k in ("context", "gsq_context") else st[r][k] - base[r][k])
                 for k in SUMS + MEANS} for r in range(W)]
         for r in range(W):
             for k in SUMS + MEANS:
+                if k.startswith("gsq") and (e + 1) % accum_every != 0:
+                    continue
                 base[r][k] = st[r][k].copy()
         merged = {}
+        acc_due = (e + 1) % accum_every == 0
         for k in SUMS:
             merged[k] = sum(own[r][k] for r in range(W))
+            if inflate and k.startswith("gsq"):
+                merged[k] = merged[k] / np.float32(W)         # every rank counted its own squares W times: the mean is the true sum
+            if k.startswith("gsq") and not acc_due:            # accumulators not exchanged this step: nothing lands, nothing is taken
+                merged[k] = None
         for k in MEANS:
             cnt = sum((own[r][k] != 0).astype(np.float32) for r in range(W))
             merged[k] = sum(own[r][k] for r in range(W)) / np.maximum(cnt, 1.0)
@@ -81,6 +120,8 @@ def run(V, N, D, W, epochs, delay, wire, seed=13):
             m, o = ready
             for r in range(W):
                 for k in SUMS + MEANS:
+                    if m[k] is None:
+                        continue
                     R = m[k] - o[r][k]
                     st[r][k] += R
                     base[r][k] += R
@@ -104,8 +145,13 @@ if __name__ == "__main__":
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--epochs", type=int, default=14)
     ap.add_argument("--wire", default="bf16")
+    ap.add_argument("--inflate", type=int, default=0, help="1: each rank counts its context-side squared gradients `ranks` times, the exchange averages them")
+    ap.add_argument("--accum-every", type=int, default=1)
+    ap.add_argument("--delays", default="0,1")
+    ap.add_argument("--hub-segments", type=int, default=0, help="S > 0: ge_sync_epoch -- the hub rows are reconciled S times per epoch")
+    ap.add_argument("--hub-workers", type=int, default=180, help="workers of the hub threshold 0.25 N_rank / workers")
     a = ap.parse_args()
-    for delay in (0, 1):
-        ratio, ref = run(a.vocab, a.nnz, a.dim, a.ranks, a.epochs, delay, a.wire)
-        print("delay %d:" % delay, " ".join("%.3f" % x for x in ratio))
+    for delay in [int(x) for x in a.delays.split(",")]:
+        ratio, ref = run(a.vocab, a.nnz, a.dim, a.ranks, a.epochs, delay, a.wire, inflate=bool(a.inflate), accum_every=a.accum_every, hub_segments=a.hub_segments, hub_workers=a.hub_workers)
+        print("delay %d:" % delay, " ".join("%.3f" % x for x in ratio), flush=True)
     print("single-process cost:", " ".join("%.4f" % x for x in ref))
