@@ -54,6 +54,9 @@ def parse():
                     help="N>1 with --exchange overlap: wavefront slots the epoch kernel leaves free for the all-reduce kernels")
     ap.add_argument("--workers", type=int, default=0, help="sequential workers (wavefronts); 0 = fill the device (cfg.workers)")
     ap.add_argument("--layout", default="", help="comma list of ge_glove_cfg.layout_flags: fixed_cuts, plain_long_rows, separate_tables, packed_records, first_placement (default: none)")
+    ap.add_argument("--shards-on-one-gpu", type=int, default=1,
+                    help="N=1 only: K > 1 puts the matrix of a K-GPU job on ONE GPU (V = K x rows-per-gpu, the K ranks' shards concatenated: "
+                         "8 = BASELINE C4 at its own size, 5 M vertices / 0.86 G nonzeros); a recorded profile leg, not the default workload")
     ap.add_argument("--hub-segments", type=int, default=0,
                     help="N>1: small exchanges of the hub rows per epoch (ge_sync_epoch); 0 = the library's default (2 x ranks, at least 8), -1 = none (one exchange per epoch for every row)")
     ap.add_argument("--no-other-form", action="store_true", help="N>1: do not time the other exchange form behind the quoted region")
@@ -186,10 +189,17 @@ def main():
         raise SystemExit("bench.py needs a gfx950 GPU: " + capi.lib().ge_last_error().decode())
 
     D = args.dim
-    V = args.rows_per_gpu * world
+    K = args.shards_on_one_gpu if world == 1 else 1
+    V = args.rows_per_gpu * world * K
     rows = parallel.shard_rows(V, world, rank)
     t_gen = time.perf_counter()
-    I, J, X, xmax = synth.synthetic_coo_shard(V, rows, args.nnz_per_gpu, seed=0xC0FFEE)
+    if K > 1:            # the whole K-GPU matrix on this GPU: every rank's shard from the generator that rank would run
+        parts = [synth.synthetic_coo_shard(V, parallel.shard_rows(V, K, k), args.nnz_per_gpu, seed=0xC0FFEE) for k in range(K)]
+        I, J, X = (np.concatenate([q[c] for q in parts]) for c in range(3))
+        xmax = parts[0][3]
+        del parts
+    else:
+        I, J, X, xmax = synth.synthetic_coo_shard(V, rows, args.nnz_per_gpu, seed=0xC0FFEE)
     t_gen = time.perf_counter() - t_gen
     n_local = int(I.shape[0])
 
@@ -317,9 +327,10 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16 rows + f32 accumulators (f32 arithmetic)", "data": "synthetic",
-            "config": {"workload": "synthetic hub-heavy co-occurrence matrix (BASELINE C4 recipe scaled to %d GPU%s): "
+            "config": {"workload": ("synthetic hub-heavy co-occurrence matrix (BASELINE C4 recipe scaled to %d GPU%s): " % (world, "s" if world > 1 else "") if K == 1
+                                    else "synthetic hub-heavy co-occurrence matrix (BASELINE C4 recipe, the whole %d-GPU job on ONE GPU): " % K) +
                                    "%d vertices, %d nonzeros/GPU, dim=%d, %s cost, %s Hogwild, per-epoch device shuffle"
-                                   % (world, "s" if world > 1 else "", V, n_local, D, args.method, opt.getName()),
+                                   % (V, n_local, D, args.method, opt.getName()),
                        "vocab": V, "nnz_per_gpu": n_local, "dim": D, "cost": args.method, "opt": args.opt,
                        "parallelism": "rows sharded x%d, context replicated + delta all-reduce every %d step(s) (rows summed, biases averaged, accumulators summed every %d syncs, %s on the wire, %s; hub rows reconciled %s per epoch in fp32)"
                                       % (world, args.sync_every, args.accum_sync_every, args.wire,

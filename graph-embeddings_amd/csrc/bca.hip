@@ -39,12 +39,24 @@ namespace {
 
 constexpr int32_t KEY_EMPTY = -1;
 
+// One 64-byte line per vertex and direction: what a pop needs of a vertex with up to six neighbours arrives in ONE memory access (degree,
+// summed weight, the neighbours themselves) instead of two dependent ones (offsets, then indices and weights); longer lists continue in
+// the CSR arrays.  Built once per ge_bca_build by k_pack_lines; read by the LDS passes.
+constexpr int LINE_NB = 6;
+struct __attribute__((aligned(64))) VLine {
+    int32_t deg;            // number of neighbours
+    int32_t pad;
+    double total;           // totalWeight of this direction (tot_out / tot_in)
+    struct { int32_t idx; float w; } nb[LINE_NB];
+};
+static_assert(sizeof(VLine) == 64, "one cache line");
 struct BcaGraph {
     const int64_t *out_ptr, *in_ptr;
     const int32_t *out_idx, *in_idx;
     const float *out_w, *in_w;
     const double *tot_out, *tot_in, *tot_und;
     int32_t V;
+    const VLine *out_line, *in_line;     // may be null (then the passes read the CSR arrays)
 };
 
 struct BcaWork {           // per-wave workspace (struct of arrays, `hc` slots each)
@@ -90,6 +102,11 @@ struct BcaParams {
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// orders the wave's LDS traffic only: global stores (the list of used slots) stay in flight across it
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ unsigned long long lanemask_lt() {
@@ -261,19 +278,20 @@ __device__ bool bca_pass(const BcaParams &p, const BcaWork &w, int32_t bookmark,
 // insert / paint); with the tables in global memory every link is a round trip to L2 or HBM -- the per-wave tables of 4 096 waves
 // are 600 MB, far past the caches -- plus a store acknowledgement at every wavefront fence: about twelve round trips, 6.8 us per
 // pop (profiles/r03_bca_*).  Here the table of one bookmark (1 024 slots: key, wet paint, the BCV value and sequence of the pass
-// under way), the active list and the list of used slots live in 20.5 KB of LDS per wavefront (seven wavefronts per CU); what is
-// left in global memory is the graph itself.  paint > 0 <=> the node is in the TreeMap (every paint ever added is >= epsilon > 0).
+// under way) and the active list live in 15 KB of LDS per wavefront (ten wavefronts per CU); what is left in global memory is the
+// graph itself and the write-only list of used slots.  paint > 0 <=> the node is in the TreeMap (every paint ever added is >= epsilon > 0).
 // A bookmark that outgrows these bounds (more than 512 nodes touched, or 384 at once in the TreeMap: 0.5 % of the rows of a
 // DBLP-like graph) is left to the global-memory kernel: status 4.
-constexpr int LDS_HC = 1024, LDS_HC_LOG2 = 10, LDS_AC = 384;
+constexpr int LDS_HC = 768, LDS_MAX = 512, LDS_AC = 384;       // slots (load <= 2/3), nodes per bookmark, nodes at once in the TreeMap
 struct BcaHot {
-    int32_t *hkey; double *paint; float *val; int16_t *seq; int32_t *alist; int16_t *touched;
+    int32_t *hkey; double *paint; float *val; int16_t *seq; int32_t *alist; int32_t *touched /* global: written here, read by the hand-over */;
 };
+__device__ __forceinline__ uint32_t lds_home(int32_t key) { return (uint32_t)(((unsigned long long)((uint32_t)key * 2654435761u) * (unsigned long long)LDS_HC) >> 32); }
 __device__ __forceinline__ int32_t lds_find(const BcaHot &t, int32_t key) {
-    uint32_t slot = ((uint32_t)key * 2654435761u) >> (32 - LDS_HC_LOG2);
+    uint32_t slot = lds_home(key);
     for (;;) {
         if (t.hkey[slot] == key) return (int32_t)slot;
-        slot = (slot + 1) & (uint32_t)(LDS_HC - 1);
+        slot = slot + 1 == (uint32_t)LDS_HC ? 0u : slot + 1;
     }
 }
 __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookmark, int mode, int32_t &n_touched, int32_t &n_seq, int32_t *status) {
@@ -283,7 +301,7 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
     auto tree_add = [&](bool act, int32_t nb, double pt) -> bool {
         int32_t slot = 0; bool inserted = false;
         if (act) {
-            uint32_t s = ((uint32_t)nb * 2654435761u) >> (32 - LDS_HC_LOG2);
+            uint32_t s = lds_home(nb);
             for (int probe = 0;; ++probe) {
                 const int32_t k = __hip_atomic_load(t.hkey + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                 if (k == nb) break;
@@ -292,7 +310,7 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
                     if (__hip_atomic_compare_exchange_strong(t.hkey + s, &expected, nb, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)) { inserted = true; break; }
                     if (expected == nb) break;
                 }
-                s = (s + 1) & (uint32_t)(LDS_HC - 1);
+                s = s + 1 == (uint32_t)LDS_HC ? 0u : s + 1;
                 if (probe > LDS_HC) break;
             }
             slot = (int32_t)s;
@@ -300,11 +318,11 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
         const unsigned long long mi = __ballot(inserted);
         if (inserted) {
             const int pos = n_touched + __popcll(mi & lanemask_lt());
-            if (pos < LDS_HC / 2) t.touched[pos] = (int16_t)slot;
+            if (pos < LDS_MAX) t.touched[pos] = slot;
             t.paint[slot] = -1.0; t.seq[slot] = -1;
         }
         n_touched += __popcll(mi);
-        if (n_touched > LDS_HC / 2) { if (lane == 0) *status = 4; return false; }
+        if (n_touched > LDS_MAX) { if (lane == 0) *status = 4; return false; }
         bool fresh = false;
         if (act) {
             const double cur = t.paint[slot];
@@ -318,7 +336,7 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
         }
         an += __popcll(mf);
         if (an > LDS_AC) { if (lane == 0) *status = 4; return false; }
-        wave_sync();
+        wave_sync_lds();
         return true;
     };
 
@@ -333,10 +351,24 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
         for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(best, m, 64); best = o < best ? o : best; }
         const int32_t focus = rfl((int)(best >> 32));
         const int32_t fpos = rfl((int)(best & 0xFFFFFFFFull));
-        // the graph reads of this pop do not depend on the table: issued first, they are under way while the table is worked on
+        // the graph reads of this pop do not depend on the table: issued first, they are under way while the table is worked on.
+        // With vertex lines the whole read is one access per direction: degree, total and the first six neighbours (lanes 0 - 5).
         double total;
         int64_t ob = 0, oe = 0, ib = 0, ie = 0;
-        if (mode == 0) { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; total = p.g.tot_out[focus]; }
+        const bool lines = p.g.out_line != nullptr;
+        int32_t l_nb = 0; float l_w = 0.0f; int32_t l_nb2 = 0; float l_w2 = 0.0f; int32_t deg1 = 0, deg2 = 0;
+        if (lines) {
+            const VLine *l1 = (mode == 1 ? p.g.in_line : p.g.out_line) + focus;
+            deg1 = l1->deg; total = l1->total;
+            if (lane < LINE_NB) { l_nb = l1->nb[lane].idx; l_w = l1->nb[lane].w; }
+            ob = (mode == 1 ? p.g.in_ptr : p.g.out_ptr)[focus]; oe = ob + deg1;      // (the offset is needed by long lists only; its load rides along)
+            if (mode == 2) {
+                const VLine *l2 = p.g.in_line + focus;
+                deg2 = l2->deg; total = p.g.tot_und[focus];
+                if (lane < LINE_NB) { l_nb2 = l2->nb[lane].idx; l_w2 = l2->nb[lane].w; }
+                ib = p.g.in_ptr[focus]; ie = ib + deg2;
+            }
+        } else if (mode == 0) { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; total = p.g.tot_out[focus]; }
         else if (mode == 1) { ob = p.g.in_ptr[focus]; oe = p.g.in_ptr[focus + 1]; total = p.g.tot_in[focus]; }
         else { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; ib = p.g.in_ptr[focus]; ie = p.g.in_ptr[focus + 1]; total = p.g.tot_und[focus]; }
         if (lane == 0) t.alist[fpos] = t.alist[an - 1];
@@ -344,7 +376,7 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
         const int32_t fslot = lds_find(t, focus);
         const double wet = t.paint[fslot];
         const int32_t old_seq = t.seq[fslot];
-        wave_sync();
+        wave_sync_lds();
         if (lane == 0) {
             t.paint[fslot] = -1.0;                                        // pollFirstEntry(): out of the TreeMap
             const float add = (float)(alpha * wet);                       // bcv.add(focus, (float)(alpha * wet))
@@ -352,7 +384,7 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
             else t.val[fslot] = t.val[fslot] + add;
         }
         if (old_seq < 0) ++n_seq;
-        wave_sync();
+        wave_sync_lds();
         if (wet < epsilon) continue;
         if (mode != 2) {
             if (oe == ob) continue;
@@ -361,13 +393,25 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
         const double spread = (1 - alpha) * wet;
         const int32_t *idx0 = mode == 1 ? p.g.in_idx : p.g.out_idx;
         const float *w0 = mode == 1 ? p.g.in_w : p.g.out_w;
+        if (lines) {                            // the neighbours that came with the line, then the rest of a long list from the CSR arrays
+            bool act = lane < LINE_NB && lane < deg1; double pt = 0;
+            if (act) { pt = spread * ((double)l_w / total); act = !(pt < epsilon); }
+            if (!tree_add(act, l_nb, pt)) return false;
+            ob += LINE_NB;
+        }
         for (int64_t k = ob; k < oe; k += 64) {
             const int64_t kk = k + lane;
             bool act = kk < oe; int32_t nb = 0; double pt = 0;
             if (act) { nb = idx0[kk]; const float weight = w0[kk]; pt = spread * ((double)weight / total); act = !(pt < epsilon); }
             if (!tree_add(act, nb, pt)) return false;
         }
-        for (int64_t k = ib; k < ie; k += 64) {
+        if (lines && mode == 2) {
+            bool act = lane < LINE_NB && lane < deg2; double pt = 0;
+            if (act) { pt = spread * ((double)l_w2 / total); act = !(pt < epsilon); }
+            if (!tree_add(act, l_nb2, pt)) return false;
+            ib += LINE_NB;
+        }
+        for (int64_t k = ib; k < ie; k += 64) {   // undirected: in-neighbours after the out-neighbours
             const int64_t kk = k + lane;
             bool act = kk < ie; int32_t nb = 0; double pt = 0;
             if (act) { nb = p.g.in_idx[kk]; const float weight = p.g.in_w[kk]; pt = spread * ((double)weight / total); act = !(pt < epsilon); }
@@ -433,8 +477,7 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
     __shared__ float s_val[LDS ? LDS_HC : 1];
     __shared__ int32_t s_alist[LDS ? LDS_AC : 1];
     __shared__ int16_t s_seq[LDS ? LDS_HC : 1];
-    __shared__ int16_t s_touched[LDS ? LDS_HC / 2 : 1];
-    const BcaHot hot{s_hkey, s_paint, s_val, s_seq, s_alist, s_touched};
+    const BcaHot hot{s_hkey, s_paint, s_val, s_seq, s_alist, w.touched};
     // table starts empty
     if constexpr (LDS) { for (int i = lane; i < LDS_HC; i += 64) s_hkey[i] = KEY_EMPTY; }
     else { for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY; }
@@ -452,20 +495,22 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
         if constexpr (LDS) {
             ok = bca_pass_lds(p, hot, bookmark, p.directed ? 0 : 2, n_touched, nf, &status);
             const int32_t nt_f = n_touched;
+            wave_sync();                                   // the list of used slots (global) is complete and visible
             if (ok) {                                      // the forward BCV leaves LDS: slot list, keys, values, sequences
                 for (int e = lane; e < nt_f; e += 64) {
-                    const int32_t sl = s_touched[e];
-                    w.touched[e] = sl; w.hkey[sl] = s_hkey[sl]; w.fval[sl] = s_val[sl]; w.fseq[sl] = s_seq[sl]; w.rseq[sl] = -1;
+                    const int32_t sl = w.touched[e];
+                    w.hkey[sl] = s_hkey[sl]; w.fval[sl] = s_val[sl]; w.fseq[sl] = s_seq[sl]; w.rseq[sl] = -1;
                     s_seq[sl] = -1;                        // the reverse pass keeps its own BCV
                 }
                 wave_sync();
             }
             if (ok && p.directed) {
                 ok = bca_pass_lds(p, hot, bookmark, 1, n_touched, nr, &status);   // DirectedWeighted: reverse = true always
+                wave_sync();
                 if (ok) {
                     for (int e = lane; e < n_touched; e += 64) {
-                        const int32_t sl = s_touched[e];
-                        if (e >= nt_f) { w.touched[e] = sl; w.hkey[sl] = s_hkey[sl]; w.fseq[sl] = -1; }   // first seen by the reverse pass
+                        const int32_t sl = w.touched[e];
+                        if (e >= nt_f) { w.hkey[sl] = s_hkey[sl]; w.fseq[sl] = -1; }   // first seen by the reverse pass
                         w.rval[sl] = s_val[sl]; w.rseq[sl] = s_seq[sl];
                     }
                     wave_sync();
@@ -625,7 +670,7 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
             if (off + n_out > p.out_cap) { fits = false; }      // the row size is known: it is re-run alone into an exact pool
             if (!fits) {
                 if (lane == 0) { p.row_n[r] = n_out; p.row_off[r] = -1; p.row_max[r] = 1.0f; atomicMax(p.status, 3); }
-                if constexpr (LDS) { for (int e = lane; e < n_touched; e += 64) s_hkey[s_touched[e]] = KEY_EMPTY; }
+                if constexpr (LDS) { for (int e = lane; e < n_touched; e += 64) s_hkey[w.touched[e]] = KEY_EMPTY; }
                 else { for (int e = lane; e < n_touched && e < p.hc / 2; e += 64) w.hkey[w.touched[e]] = KEY_EMPTY; }
                 wave_sync();
                 continue;
@@ -693,7 +738,7 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
             if (!ok) atomicMax(p.status, LDS ? 4 : (status ? status : 1));
         }
         // reset the table for the next bookmark
-        if constexpr (LDS) { for (int e = lane; e < n_touched && e < LDS_HC / 2; e += 64) s_hkey[s_touched[e]] = KEY_EMPTY; }
+        if constexpr (LDS) { for (int e = lane; e < n_touched && e < LDS_MAX; e += 64) s_hkey[w.touched[e]] = KEY_EMPTY; }
         else {
             for (int e = lane; e < n_touched && e < p.hc / 2; e += 64) w.hkey[w.touched[e]] = KEY_EMPTY;
             if (!ok && status == 1) for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY;   // touched[] was truncated
@@ -715,6 +760,19 @@ __global__ void k_totals(BcaGraph g, double *tot_out, double *tot_in, double *to
     for (int64_t k = g.in_ptr[v]; k < g.in_ptr[v + 1]; ++k) { b += g.in_w[k]; u += g.in_w[k]; }
     tot_in[v] = b;
     tot_und[v] = u;
+}
+
+__global__ void k_pack_lines(BcaGraph g, VLine *out_line, VLine *in_line) {
+    const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.V) return;
+    for (int dir = 0; dir < 2; ++dir) {
+        const int64_t b = dir ? g.in_ptr[v] : g.out_ptr[v], e = dir ? g.in_ptr[v + 1] : g.out_ptr[v + 1];
+        const int32_t *idx = dir ? g.in_idx : g.out_idx; const float *w = dir ? g.in_w : g.out_w;
+        VLine l;
+        l.deg = (int32_t)(e - b); l.pad = 0; l.total = dir ? g.tot_in[v] : g.tot_out[v];
+        for (int k = 0; k < LINE_NB; ++k) { const bool have = b + k < e; l.nb[k].idx = have ? idx[b + k] : 0; l.nb[k].w = have ? w[b + k] : 0.0f; }
+        (dir ? in_line : out_line)[v] = l;
+    }
 }
 
 // rows from the pool -> bookmark order
@@ -820,9 +878,19 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     if ((st = upload(in_nbrs->weight, (size_t)Ei, &d_iw)) != GE_OK) return st;    dev.keep(d_iw);
     double *d_tot = nullptr;
     GE_HIP(hipMalloc((void **)&d_tot, sizeof(double) * 3 * (size_t)V)); dev.keep(d_tot);
-    p.g = BcaGraph{d_optr, d_iptr, d_oidx, d_iidx, d_ow, d_iw, d_tot, d_tot + V, d_tot + 2 * (size_t)V, V};
+    p.g = BcaGraph{d_optr, d_iptr, d_oidx, d_iidx, d_ow, d_iw, d_tot, d_tot + V, d_tot + 2 * (size_t)V, V, nullptr, nullptr};
     hipLaunchKernelGGL(k_totals, dim3((V + 255) / 256), dim3(256), 0, 0, p.g, d_tot, d_tot + V, d_tot + 2 * (size_t)V);
     GE_HIP(hipGetLastError());
+    {   // vertex lines (128 bytes per vertex): without them a pop costs two dependent reads of the graph; GE_BCA_LINES=0 keeps the CSR reads
+        const char *le = std::getenv("GE_BCA_LINES");
+        VLine *d_lines = nullptr;
+        if (!(le && std::atoi(le) == 0) && hipMalloc((void **)&d_lines, sizeof(VLine) * 2 * (size_t)V) == hipSuccess) {
+            dev.keep(d_lines);
+            hipLaunchKernelGGL(k_pack_lines, dim3((V + 255) / 256), dim3(256), 0, 0, p.g, d_lines, d_lines + V);
+            GE_HIP(hipGetLastError());
+            p.g.out_line = d_lines; p.g.in_line = d_lines + V;
+        } else (void)hipGetLastError();
+    }
 
     p.alpha = cfg->alpha; p.epsilon = cfg->epsilon; p.directed = cfg->directed ? 1 : 0; p.normalize = cfg->normalize;
     p.row_begin = rb; p.row_end = re;
@@ -868,10 +936,10 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     auto make_work = [&](Work &w, bool lds) -> ge_status {
         free_work(w);
         w.lds = lds;
-        if (lds) { w.hc = LDS_HC; w.ac = LDS_AC; }
+        if (lds) { w.hc = 2 * LDS_MAX; w.ac = LDS_AC; }                  // the workspace of the emission: 2 x 512 slots (a power of two; LDS slots index it)
         else { int hl = 0; while ((1ll << hl) < hc) ++hl; hc = 1ll << hl; w.hc = hc; w.ac = ac; }
         w.stride = (work_bytes(w.hc, w.ac) + 255) / 256 * 256;
-        w.n_waves = std::min<int64_t>((int64_t)cus * (lds ? 7 : 16), n_rows);
+        w.n_waves = std::min<int64_t>((int64_t)cus * (lds ? 10 : 16), n_rows);
         while (w.n_waves > 1 && w.n_waves * w.stride > (int64_t)6 << 30) w.n_waves /= 2;
         if (hipMalloc((void **)&w.mem, (size_t)(w.n_waves * w.stride)) != hipSuccess) {
             (void)hipGetLastError(); w.mem = nullptr;
@@ -946,30 +1014,26 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
         GE_HIP(hipMalloc((void **)&d_redo, sizeof(int32_t) * std::max<size_t>(redo.size(), 1))); dev.keep(d_redo);
         const Work *wredo = &wmain;
         if (!big.empty()) {
-            // the global-memory kernel learns the sizes of the big rows (no pool: every row reports its size), growing its tables as needed
-            GE_HIP(hipMemcpy(d_redo, big.data(), sizeof(int32_t) * big.size(), hipMemcpyHostToDevice));
-            for (int attempt = 0;; ++attempt) {
-                if (attempt > 12) return ge::fail(GE_ERR_OVERFLOW, "BCA work buffers kept overflowing (table %lld, active list %lld)", (long long)hc, (long long)ac);
-                if ((st = make_work(wglob, false)) != GE_OK) return st;
-                if ((st = run(wglob, d_redo, (int32_t)big.size(), nullptr, nullptr, 0, 0, &status, &used)) != GE_OK) return st;
-                if (status == 1 || status == 2) { grow(status); continue; }
-                break;
-            }
-            GE_HIP(hipMemcpy(h_n.data(), d_row_n, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost));
+            // a bookmark never yields more entries than the global-memory kernel's table holds nodes (hc / 2): that bounds the big rows,
+            // whose sizes are unknown (should the tables have to grow, the launch below is repeated with the larger bound)
+            if ((st = make_work(wglob, false)) != GE_OK) return st;
             wredo = &wglob;
         }
-        int64_t need = 0;
-        for (int32_t r : redo) need += h_n[(size_t)r];
-        const int64_t cap2 = need + 64;
-        bool good = hipMalloc((void **)&d_pJ2, sizeof(int32_t) * (size_t)cap2) == hipSuccess;
-        if (d_pJ2) dev.keep(d_pJ2);
-        good = good && hipMalloc((void **)&d_pX2, sizeof(float) * (size_t)cap2) == hipSuccess;
-        if (d_pX2) dev.keep(d_pX2);
-        if (!good) return ge::fail(GE_ERR_OOM, "device allocation failed for the second BCA pool (%lld entries)", (long long)cap2);
+        auto row_bound = [&](int32_t r) -> int64_t { return h_off[(size_t)r] == -2 ? std::min<int64_t>(wglob.hc / 2, V) : (int64_t)h_n[(size_t)r]; };
         GE_HIP(hipMemcpy(d_redo, redo.data(), sizeof(int32_t) * redo.size(), hipMemcpyHostToDevice));
         // second-pool offsets are stored shifted by pool_cap so that one gather kernel can tell the pools apart
+        int64_t cap2 = 0;
         for (int attempt = 0;; ++attempt) {
             if (attempt > 12) return ge::fail(GE_ERR_OVERFLOW, "BCA work buffers kept overflowing (table %lld, active list %lld)", (long long)hc, (long long)ac);
+            int64_t need = 0;
+            for (int32_t r : redo) need += row_bound(r);
+            cap2 = need + 64;
+            d_pJ2 = nullptr; d_pX2 = nullptr;
+            bool good = hipMalloc((void **)&d_pJ2, sizeof(int32_t) * (size_t)cap2) == hipSuccess;
+            if (d_pJ2) dev.keep(d_pJ2);
+            good = good && hipMalloc((void **)&d_pX2, sizeof(float) * (size_t)cap2) == hipSuccess;
+            if (d_pX2) dev.keep(d_pX2);
+            if (!good) return ge::fail(GE_ERR_OOM, "device allocation failed for the second BCA pool (%lld entries)", (long long)cap2);
             if ((st = run(*wredo, d_redo, (int32_t)redo.size(), d_pJ2 - pool_cap, d_pX2 - pool_cap, pool_cap + cap2, (unsigned long long)pool_cap, &status, &used)) != GE_OK) return st;
             if (!wredo->lds && (status == 1 || status == 2)) { grow(status); if ((st = make_work(wglob, false)) != GE_OK) return st; wredo = &wglob; continue; }
             break;

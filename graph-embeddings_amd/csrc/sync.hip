@@ -174,8 +174,14 @@ __global__ __launch_bounds__(256) void k_sync_turn_flat4(float *__restrict__ tab
 // the ranks' hub columns: a few thousand rows, megabytes), so each such exchange is one small fp32 all-reduce.
 // One wavefront per hub row.  buf = [rows H x D | accumulator rows H x D | gradSqCBias H | cBias H | count H].
 // take: buf = table - base (fp32, exact: nothing of these rows is ever in flight in the large exchange, whose take sees 0 for them)
+// ROW16: the parameter rows are bf16 (GE_DTYPE_BF16 handles): a row's value is its fp32 master row where the column is a hub ON THIS
+// RANK, else the bf16 table entry; a landed value goes back the same way (the bf16 entry with stochastic rounding, whose error the large
+// exchange's take then finds in value - base and feeds back, as for every bf16 row).
+__device__ __forceinline__ uint32_t hub_mix32(uint32_t x) { x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13; x *= 0xC2B2AE3Du; x ^= x >> 16; return x; }
+template <bool ROW16>
 __global__ __launch_bounds__(256) void k_hub_take(const int32_t *__restrict__ list, int32_t H, int32_t D,
-                                                  const float *__restrict__ rows, int64_t rows_stride, const float *__restrict__ rows_base,
+                                                  const void *__restrict__ rows_, int64_t rows_stride, const float *__restrict__ rows_base,
+                                                  const float *__restrict__ masters, const int32_t *__restrict__ master_index,
                                                   const float *__restrict__ acc, int64_t acc_stride, const float *__restrict__ acc_base,
                                                   const float *__restrict__ accb, int64_t accb_stride, const float *__restrict__ accb_base,
                                                   const float *__restrict__ bias, int64_t bias_stride, const float *__restrict__ bias_base,
@@ -184,9 +190,13 @@ __global__ __launch_bounds__(256) void k_hub_take(const int32_t *__restrict__ li
     const int32_t h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= H) return;
     const int64_t v = list[h];
+    const int32_t mi = ROW16 ? master_index[v] : -1;
     float *const b_rows = buf, *const b_acc = buf + (int64_t)H * D, *const b_accb = b_acc + (int64_t)H * D, *const b_bias = b_accb + H, *const b_cnt = b_bias + H;
     for (int32_t d = lane; d < D; d += 64) {
-        b_rows[(int64_t)h * D + d] = rows[v * rows_stride + d] - rows_base[v * D + d];
+        float val;
+        if (ROW16) val = mi >= 0 ? masters[(int64_t)mi * D + d] : bf16_to_f32(reinterpret_cast<const uint16_t *>(rows_)[v * rows_stride + d]);
+        else val = reinterpret_cast<const float *>(rows_)[v * rows_stride + d];
+        b_rows[(int64_t)h * D + d] = val - rows_base[v * D + d];
         b_acc[(int64_t)h * D + d] = acc[v * acc_stride + d] - acc_base[v * D + d];
     }
     if (lane == 0) {
@@ -196,8 +206,10 @@ __global__ __launch_bounds__(256) void k_hub_take(const int32_t *__restrict__ li
     }
 }
 // land: base += the summed deltas (cBias: the mean over the ranks that moved it); table = base -- every rank's hub rows ARE the consensus
+template <bool ROW16>
 __global__ __launch_bounds__(256) void k_hub_land(const int32_t *__restrict__ list, int32_t H, int32_t D,
-                                                  float *__restrict__ rows, int64_t rows_stride, float *__restrict__ rows_base,
+                                                  void *__restrict__ rows_, int64_t rows_stride, float *__restrict__ rows_base,
+                                                  float *__restrict__ masters, const int32_t *__restrict__ master_index, uint32_t seed,
                                                   float *__restrict__ acc, int64_t acc_stride, float *__restrict__ acc_base,
                                                   float *__restrict__ accb, int64_t accb_stride, float *__restrict__ accb_base,
                                                   float *__restrict__ bias, int64_t bias_stride, float *__restrict__ bias_base,
@@ -206,10 +218,18 @@ __global__ __launch_bounds__(256) void k_hub_land(const int32_t *__restrict__ li
     const int32_t h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= H) return;
     const int64_t v = list[h];
+    const int32_t mi = ROW16 ? master_index[v] : -1;
     const float *const b_rows = buf, *const b_acc = buf + (int64_t)H * D, *const b_accb = b_acc + (int64_t)H * D, *const b_bias = b_accb + H, *const b_cnt = b_bias + H;
     for (int32_t d = lane; d < D; d += 64) {
         const float c = rows_base[v * D + d] + b_rows[(int64_t)h * D + d];
-        rows_base[v * D + d] = c; rows[v * rows_stride + d] = c;
+        rows_base[v * D + d] = c;
+        if (ROW16) {
+            if (mi >= 0) masters[(int64_t)mi * D + d] = c;
+            else {
+                const uint32_t bits = __float_as_uint(c), rnd = hub_mix32((uint32_t)(h * D + d) * 0x9E3779B1u + seed) >> 16;
+                reinterpret_cast<uint16_t *>(rows_)[v * rows_stride + d] = (uint16_t)(((bits & 0x7f800000u) == 0x7f800000u) ? bits >> 16 : (bits + rnd) >> 16);
+            }
+        } else reinterpret_cast<float *>(rows_)[v * rows_stride + d] = c;
         const float a = acc_base[v * D + d] + b_acc[(int64_t)h * D + d];
         acc_base[v * D + d] = a; acc[v * acc_stride + d] = a;
     }
@@ -494,13 +514,22 @@ ge_status hub_exchange(ge_sync *s) {
     const Entry &er = s->ent[0], &eb = s->ent[1], &ea = s->ent[2], &eab = s->ent[3];
     const int32_t H = s->n_hub, D = s->lay.dim;
     const dim3 g((unsigned)((H + 3) / 4)), b(256);
-    hipLaunchKernelGGL(k_hub_take, g, b, 0, s->main, s->hub_list, H, D, er.table, er.t_stride, er.base, ea.table, ea.t_stride, ea.base,
-                       eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf);
+    const bool r16 = er.bf16_rows;
+    void *rows = r16 ? (void *)s->lay.table : (void *)er.table;
+    const int64_t rstride = r16 ? (int64_t)s->lay.row_stride : er.t_stride;
+    if (r16) hipLaunchKernelGGL(k_hub_take<true>, g, b, 0, s->main, s->hub_list, H, D, rows, rstride, er.base, s->lay.hub_rows, s->lay.hub_index, ea.table, ea.t_stride, ea.base,
+                                eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf);
+    else hipLaunchKernelGGL(k_hub_take<false>, g, b, 0, s->main, s->hub_list, H, D, rows, rstride, er.base, (const float *)nullptr, (const int32_t *)nullptr, ea.table, ea.t_stride, ea.base,
+                            eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf);
     GE_HIP(hipGetLastError());
     ge_status st = allreduce_f32_small(s, s->hub_buf, (int64_t)H * (2 * D + 3));
     if (st != GE_OK) return st;
-    hipLaunchKernelGGL(k_hub_land, g, b, 0, s->main, s->hub_list, H, D, er.table, er.t_stride, er.base, ea.table, ea.t_stride, ea.base,
-                       eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf);
+    s->seed = s->seed * 1664525u + 1013904223u;
+    const uint32_t seed = s->seed ^ ((uint32_t)s->cfg.rank * 0x9E3779B1u);
+    if (r16) hipLaunchKernelGGL(k_hub_land<true>, g, b, 0, s->main, s->hub_list, H, D, rows, rstride, er.base, s->lay.hub_rows, s->lay.hub_index, seed, ea.table, ea.t_stride, ea.base,
+                                eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf);
+    else hipLaunchKernelGGL(k_hub_land<false>, g, b, 0, s->main, s->hub_list, H, D, rows, rstride, er.base, (float *)nullptr, (const int32_t *)nullptr, seed, ea.table, ea.t_stride, ea.base,
+                            eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf);
     GE_HIP(hipGetLastError());
     return GE_OK;
 }
@@ -673,9 +702,9 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
             }
         }
         // The hub rows of the small exchanges (ge_sync_epoch): the union of the ranks' hub columns (every rank flags its own in a
-        // [V] vector, the vector is summed).  fp32 rows only: a bf16 handle keeps the fp32 masters of ITS hubs, and a column that is a
-        // hub on one rank and an ordinary bf16 row on another has no common exact representation -- such handles exchange once per epoch.
-        if (s->lay.dtype != GE_DTYPE_BF16) {
+        // [V] vector, the vector is summed).  A bf16 handle keeps the fp32 masters of ITS hubs, and a column that is a
+        // hub on one rank and an ordinary bf16 row on another is written back as each rank stores it (k_hub_land).
+        {
             const std::vector<int32_t> *mine = ge::glove_hub_columns(h);
             float *flags = nullptr; int32_t *tmp = nullptr;
             GE_TRYS(hipMalloc((void **)&flags, sizeof(float) * (size_t)std::max<int64_t>(V, 1)));

@@ -448,8 +448,9 @@ ge_status ge_sync_sync(ge_sync *s);
  * accumulators summed, cBias averaged over the ranks that moved it).  Without it eight ranks that each push a busy row for a whole
  * epoch from the same start overshoot where one GPU settles (measured: DESIGN.md 7); inside a GPU the same rows are held together by
  * publishing deltas every few updates, across GPUs by this.  ge_sync_turn / ge_sync_sync follow as before (they find nothing left to
- * do for the hub rows).  *cost_sum as ge_glove_epoch.  fp32 rows; a bf16 handle (whose hub rows have per-rank fp32 masters), a
- * one-rank run and a run without hub columns get one plain ge_glove_epoch. */
+ * do for the hub rows).  *cost_sum as ge_glove_epoch.  fp32 and bf16 rows (a bf16 handle reads and writes a hub row where IT keeps
+ * it: the fp32 master row of a column that is a hub on this rank, else the bf16 table entry, stochastically rounded).  A one-rank run
+ * and a run without hub columns get one plain ge_glove_epoch. */
 ge_status ge_sync_epoch(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum);
 /* Ends a run: lands what is in flight, exchanges everything not sent yet, then every rank takes rank src's fp32 tables. */
 ge_status ge_sync_replicate(ge_sync *s, int32_t src);

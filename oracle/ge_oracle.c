@@ -921,42 +921,6 @@ float geo_opt_job(int opt_kind, int iteration, int32_t D, int64_t n, const int32
     return cost;
 }
 
-/* One rank's pass of a row-SHARDED run (no counterpart in the reference, which is one JVM; product semantics of ge_sync,
- * DESIGN.md 7): Adagrad.createJob's update with the increments of the CONTEXT-side accumulators multiplied by `ctx_scale` (the
- * number of ranks whose gradients the replicated accumulator stands in for between two exchanges).  ctx_scale = 1 is
- * adagrad_update exactly.  Used by tests/tools/multirank_sim.py and the sharded parity tests. */
-static inline void adagrad_update_shard(int kind, double xmax, int32_t D, int32_t bu, int32_t bv, float Xij,
-                                        float *focus, float *context, float *fbias, float *cbias,
-                                        float *gsf, float *gsc, float *gsfb, float *gscb, float *cost, float ctx_scale) {
-    float *foc = focus + (int64_t)bu * D, *ctx = context + (int64_t)bv * D;
-    float *g1s = gsf + (int64_t)bu * D,  *g2s = gsc + (int64_t)bv * D;
-    const float ic = inner_cost(kind, D, foc, ctx, fbias[bu], cbias[bv], Xij);
-    float wc = weighted_cost(kind, xmax, ic, Xij);
-    *cost = (float)((double)*cost + 0.5 * wc * ic);
-    for (int32_t d = 0; d < D; d++) {
-        const float grad1 = wc * ctx[d];
-        const float grad2 = wc * foc[d];
-        foc[d] = (float)((double)foc[d] - grad1 / sqrt((double)g1s[d]) * LEARNING_RATE);
-        ctx[d] = (float)((double)ctx[d] - grad2 / sqrt((double)g2s[d]) * LEARNING_RATE);
-        g1s[d] += grad1 * grad1;
-        g2s[d] += ctx_scale * (grad2 * grad2);
-    }
-    fbias[bu] = (float)((double)fbias[bu] - wc / sqrt((double)gsfb[bu]));
-    cbias[bv] = (float)((double)cbias[bv] - wc / sqrt((double)gscb[bv]));
-    wc *= wc;
-    gsfb[bu] += wc;
-    gscb[bv] += ctx_scale * wc;
-}
-float geo_adagrad_job_shard(int32_t D, int64_t n, const int32_t *I, const int32_t *J, const float *X,
-                            double xmax, int cost_kind,
-                            float *focus, float *context, float *fbias, float *cbias,
-                            float *gsf, float *gsc, float *gsfb, float *gscb, float ctx_scale) {
-    float cost = 0;
-    for (int64_t k = 0; k < n; k++)
-        adagrad_update_shard(cost_kind, xmax, D, I[k], J[k], X[k], focus, context, fbias, cbias, gsf, gsc, gsfb, gscb, &cost, ctx_scale);
-    return cost;
-}
-
 float geo_adagrad_job(int32_t D, int64_t n, const int32_t *I, const int32_t *J, const float *X,
                       double xmax, int cost_kind,
                       float *focus, float *context, float *fbias, float *cbias,

@@ -131,11 +131,6 @@ float geo_adagrad_job(int32_t D, int64_t n,
 
 /* One job of any optimiser over (I,J,X) in the given order on caller-owned state; `iteration` is createJob's
  * argument (Adam's bias correction).  s1* = gradSq (Adagrad) or M1 (Adam/AMSGrad); s2* = M2 (ignored by Adagrad). */
-/* one rank's pass of a row-sharded run: context-side accumulator increments times ctx_scale (product semantics of ge_sync) */
-float geo_adagrad_job_shard(int32_t D, int64_t n, const int32_t *I, const int32_t *J, const float *X,
-                            double xmax, int cost_kind,
-                            float *focus, float *context, float *fbias, float *cbias,
-                            float *gsf, float *gsc, float *gsfb, float *gscb, float ctx_scale);
 float geo_opt_job(int opt_kind, int iteration, int32_t D, int64_t n,
                   const int32_t *I, const int32_t *J, const float *X, double xmax, int cost_kind,
                   float *focus, float *context, float *fbias, float *cbias,

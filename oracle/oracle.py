@@ -132,8 +132,6 @@ def lib():
     L.geo_adagrad_job.argtypes = [C.c_int32, C.c_int64, i32p, i32p, f32p, C.c_double, C.c_int,
                                   f32p, f32p, f32p, f32p, f32p, f32p, f32p, f32p]
     L.geo_adagrad_job.restype = C.c_float
-    L.geo_adagrad_job_shard.argtypes = [C.c_int32, C.c_int64, i32p, i32p, f32p, C.c_double, C.c_int] + [f32p] * 8 + [C.c_float]
-    L.geo_adagrad_job_shard.restype = C.c_float
     L.geo_format_11_6E.argtypes = [C.c_double, C.c_char_p, C.c_int]; L.geo_format_11_6E.restype = C.c_int
     u16p = C.POINTER(C.c_uint16)
     L.geo_sim_pair.argtypes = [C.POINTER(SimCfg), u16p, C.c_int32, u16p, C.c_int32, C.POINTER(C.c_int)]; L.geo_sim_pair.restype = C.c_double
@@ -309,17 +307,13 @@ class Glove:
         lib().geo_glove_set_iteration(self._h, it)
 
 
-def adagrad_job(D, I, J, X, xmax, cost, state, ctx_acc_scale=None):
-    """Bare Adagrad.createJob loop over (I,J,X) in the given order on a state dict (in place).  ctx_acc_scale: one rank's pass of a
-    row-sharded run (increments of the context-side accumulators times that factor; ge_sync's product semantics)."""
+def adagrad_job(D, I, J, X, xmax, cost, state):
+    """Bare Adagrad.createJob loop over (I,J,X) in the given order on a state dict (in place)."""
     I = np.ascontiguousarray(I, np.int32); J = np.ascontiguousarray(J, np.int32)
     X = np.ascontiguousarray(X, np.float32)
     names = ("focus", "context", "fbias", "cbias", "gsq_focus", "gsq_context", "gsq_fbias", "gsq_cbias")
     for k in names:
         assert state[k].dtype == np.float32 and state[k].flags.c_contiguous
-    if ctx_acc_scale is not None:
-        return lib().geo_adagrad_job_shard(D, len(I), _p(I, C.c_int32), _p(J, C.c_int32), _p(X, C.c_float),
-                                           float(xmax), cost, *[_p(state[k], C.c_float) for k in names], C.c_float(ctx_acc_scale))
     return lib().geo_adagrad_job(D, len(I), _p(I, C.c_int32), _p(J, C.c_int32), _p(X, C.c_float),
                                  float(xmax), cost, *[_p(state[k], C.c_float) for k in names])
 

@@ -339,22 +339,26 @@ def _run_rank_threads(world, V, N, D, epochs, exchange, wire, dtype="f32", lazy_
     return cost.sum(axis=1) / len(I), out, err, alive
 
 
-@pytest.mark.parametrize("exchange", ["sync", "overlap"])
-def test_eight_ranks_share_one_gpu(gpu, exchange):
-    """C4's shape (dim 200, fp32 rows, bf16 wire, accumulators every 2nd exchange) with EIGHT contributors per element."""
-    costs, out, err, alive = _run_rank_threads(W8["world"], W8["V"], W8["N"], W8["D"], W8["epochs"], exchange, "bf16")
+@pytest.mark.parametrize("exchange,dtype", [("sync", "f32"), ("overlap", "f32"), ("sync", "bf16")])
+def test_eight_ranks_share_one_gpu(gpu, exchange, dtype):
+    """C4's shape (dim 200, fp32 rows, bf16 wire, accumulators every 2nd exchange) with EIGHT contributors per element, through
+    ge_sync_epoch (hub rows reconciled between the segments of the epoch) + the large exchange; and the same with bf16 rows (C5)."""
+    costs, out, err, alive = _run_rank_threads(W8["world"], W8["V"], W8["N"], W8["D"], W8["epochs"], exchange, "bf16", dtype=dtype)
     assert not any(alive) and all(e is None for e in err), err
     for r in range(1, W8["world"]):
         for k in CTX:
+            if dtype == "bf16" and k == "context":            # bf16 rows live partly in per-rank fp32 master rows: equal up to one bf16 rounding
+                np.testing.assert_allclose(out[0][k], out[r][k], rtol=2.0 ** -7, atol=1e-5)
+                continue
             assert np.array_equal(out[0][k], out[r][k]), "rank %d's %s differs from rank 0's after replicate()" % (r, k)
     ref = _oracle8()
     ratio = np.array(costs) / np.array(ref)
-    print("eight ranks %s D=%d: cost / oracle %s" % (exchange, W8["D"], np.round(ratio, 3).tolist()))
+    print("eight ranks %s %s D=%d: cost / oracle %s" % (exchange, dtype, W8["D"], np.round(ratio, 3).tolist()))
     assert np.all(np.isfinite(costs)) and costs[-1] < costs[2] < costs[0]
     # bands: the blocked order and eight shards shift the first two epochs; from the third the sharded run tracks the
     # single-process oracle (synchronous: every rank sees the others' moves after each step; overlapped: one step late)
     np.testing.assert_allclose(costs[:2], ref[:2], rtol=0.25)
-    np.testing.assert_allclose(costs[2:], ref[2:], rtol=0.06 if exchange == "sync" else 0.10)
+    np.testing.assert_allclose(costs[2:], ref[2:], rtol=0.06 if (exchange == "sync" and dtype == "f32") else 0.10)
 
 
 def test_eight_ranks_need_the_hub_rows_reconciled_inside_the_epoch(gpu):

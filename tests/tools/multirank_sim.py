@@ -39,7 +39,7 @@ def model_cost(I, J, X, xmax, focus, context, fb, cb, block=200_000):
     return tot / len(I)
 
 
-def run(V, N, D, W, epochs, delay, wire, seed=13, inflate=False, accum_every=1, hub_segments=0, hub_workers=180):
+def run(V, N, D, W, epochs, delay, wire, seed=13, accum_every=1, hub_segments=0, hub_workers=180):
     I, J, X, xmax = synth.synthetic_coo(V, N, seed=seed)
     N = len(I)                                             # duplicates are merged by the generator
     single = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
@@ -93,7 +93,7 @@ def run(V, N, D, W, epochs, delay, wire, seed=13, inflate=False, accum_every=1, 
           for r in range(W):
             si, sj, sx = shards[r]
             p = rngs[r].permutation(len(si))
-            tot += float(O.adagrad_job(D, si[p], sj[p], sx[p], xmax, O.COST_GLOVE, st[r], ctx_acc_scale=float(W) if inflate else None))
+            tot += float(O.adagrad_job(D, si[p], sj[p], sx[p], xmax, O.COST_GLOVE, st[r]))
         # snapshot this epoch's deltas
         own = [{k: (narrow(st[r][k] - base[r][k]) if k in ("context", "gsq_context") else st[r][k] - base[r][k])
                 for k in SUMS + MEANS} for r in range(W)]
@@ -106,8 +106,6 @@ def run(V, N, D, W, epochs, delay, wire, seed=13, inflate=False, accum_every=1, 
         acc_due = (e + 1) % accum_every == 0
         for k in SUMS:
             merged[k] = sum(own[r][k] for r in range(W))
-            if inflate and k.startswith("gsq"):
-                merged[k] = merged[k] / np.float32(W)         # every rank counted its own squares W times: the mean is the true sum
             if k.startswith("gsq") and not acc_due:            # accumulators not exchanged this step: nothing lands, nothing is taken
                 merged[k] = None
         for k in MEANS:
@@ -145,13 +143,12 @@ if __name__ == "__main__":
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--epochs", type=int, default=14)
     ap.add_argument("--wire", default="bf16")
-    ap.add_argument("--inflate", type=int, default=0, help="1: each rank counts its context-side squared gradients `ranks` times, the exchange averages them")
     ap.add_argument("--accum-every", type=int, default=1)
     ap.add_argument("--delays", default="0,1")
     ap.add_argument("--hub-segments", type=int, default=0, help="S > 0: ge_sync_epoch -- the hub rows are reconciled S times per epoch")
     ap.add_argument("--hub-workers", type=int, default=180, help="workers of the hub threshold 0.25 N_rank / workers")
     a = ap.parse_args()
     for delay in [int(x) for x in a.delays.split(",")]:
-        ratio, ref = run(a.vocab, a.nnz, a.dim, a.ranks, a.epochs, delay, a.wire, inflate=bool(a.inflate), accum_every=a.accum_every, hub_segments=a.hub_segments, hub_workers=a.hub_workers)
+        ratio, ref = run(a.vocab, a.nnz, a.dim, a.ranks, a.epochs, delay, a.wire, accum_every=a.accum_every, hub_segments=a.hub_segments, hub_workers=a.hub_workers)
         print("delay %d:" % delay, " ".join("%.3f" % x for x in ratio), flush=True)
     print("single-process cost:", " ".join("%.4f" % x for x in ref))
