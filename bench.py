@@ -339,6 +339,10 @@ def main():
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "traffic": traffic,
+                         # the counters (FETCH_SIZE x2 + WRITE_SIZE) count L2 <-> fabric requests, Infinity-Cache hits included, and were taken in
+                         # the committed profile run (another box, same kernel instance / workload / layout): bytes per launch carry over, the
+                         # time divided into them below is THIS run's
+                         "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes of this kernel instance, workload and layout)" if traffic else None,
                          "frac_traffic": (traffic / avg_kernel_s / 1e9 / 8000.0) if traffic else None,
                          "kernel": kernel, "kernel_ms": avg_kernel_s * 1e3,
                          "schedule_bytes_per_launch": sched, "schedule_bytes_per_update": sched / max(n_local, 1),

@@ -39,24 +39,12 @@ namespace {
 
 constexpr int32_t KEY_EMPTY = -1;
 
-// One 64-byte line per vertex and direction: what a pop needs of a vertex with up to six neighbours arrives in ONE memory access (degree,
-// summed weight, the neighbours themselves) instead of two dependent ones (offsets, then indices and weights); longer lists continue in
-// the CSR arrays.  Built once per ge_bca_build by k_pack_lines; read by the LDS passes.
-constexpr int LINE_NB = 6;
-struct __attribute__((aligned(64))) VLine {
-    int32_t deg;            // number of neighbours
-    int32_t pad;
-    double total;           // totalWeight of this direction (tot_out / tot_in)
-    struct { int32_t idx; float w; } nb[LINE_NB];
-};
-static_assert(sizeof(VLine) == 64, "one cache line");
 struct BcaGraph {
     const int64_t *out_ptr, *in_ptr;
     const int32_t *out_idx, *in_idx;
     const float *out_w, *in_w;
     const double *tot_out, *tot_in, *tot_und;
     int32_t V;
-    const VLine *out_line, *in_line;     // may be null (then the passes read the CSR arrays)
 };
 
 struct BcaWork {           // per-wave workspace (struct of arrays, `hc` slots each)
@@ -352,23 +340,11 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
         const int32_t focus = rfl((int)(best >> 32));
         const int32_t fpos = rfl((int)(best & 0xFFFFFFFFull));
         // the graph reads of this pop do not depend on the table: issued first, they are under way while the table is worked on.
-        // With vertex lines the whole read is one access per direction: degree, total and the first six neighbours (lanes 0 - 5).
+        // (One 64-byte line per vertex holding degree, total and the first six neighbours -- one access instead of two dependent ones
+        // -- was tried: bit-identical, and 6 % SLOWER, 97.8 against 92.0 ms; the second read is not what a pop waits for.)
         double total;
         int64_t ob = 0, oe = 0, ib = 0, ie = 0;
-        const bool lines = p.g.out_line != nullptr;
-        int32_t l_nb = 0; float l_w = 0.0f; int32_t l_nb2 = 0; float l_w2 = 0.0f; int32_t deg1 = 0, deg2 = 0;
-        if (lines) {
-            const VLine *l1 = (mode == 1 ? p.g.in_line : p.g.out_line) + focus;
-            deg1 = l1->deg; total = l1->total;
-            if (lane < LINE_NB) { l_nb = l1->nb[lane].idx; l_w = l1->nb[lane].w; }
-            ob = (mode == 1 ? p.g.in_ptr : p.g.out_ptr)[focus]; oe = ob + deg1;      // (the offset is needed by long lists only; its load rides along)
-            if (mode == 2) {
-                const VLine *l2 = p.g.in_line + focus;
-                deg2 = l2->deg; total = p.g.tot_und[focus];
-                if (lane < LINE_NB) { l_nb2 = l2->nb[lane].idx; l_w2 = l2->nb[lane].w; }
-                ib = p.g.in_ptr[focus]; ie = ib + deg2;
-            }
-        } else if (mode == 0) { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; total = p.g.tot_out[focus]; }
+        if (mode == 0) { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; total = p.g.tot_out[focus]; }
         else if (mode == 1) { ob = p.g.in_ptr[focus]; oe = p.g.in_ptr[focus + 1]; total = p.g.tot_in[focus]; }
         else { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; ib = p.g.in_ptr[focus]; ie = p.g.in_ptr[focus + 1]; total = p.g.tot_und[focus]; }
         if (lane == 0) t.alist[fpos] = t.alist[an - 1];
@@ -393,23 +369,11 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
         const double spread = (1 - alpha) * wet;
         const int32_t *idx0 = mode == 1 ? p.g.in_idx : p.g.out_idx;
         const float *w0 = mode == 1 ? p.g.in_w : p.g.out_w;
-        if (lines) {                            // the neighbours that came with the line, then the rest of a long list from the CSR arrays
-            bool act = lane < LINE_NB && lane < deg1; double pt = 0;
-            if (act) { pt = spread * ((double)l_w / total); act = !(pt < epsilon); }
-            if (!tree_add(act, l_nb, pt)) return false;
-            ob += LINE_NB;
-        }
         for (int64_t k = ob; k < oe; k += 64) {
             const int64_t kk = k + lane;
             bool act = kk < oe; int32_t nb = 0; double pt = 0;
             if (act) { nb = idx0[kk]; const float weight = w0[kk]; pt = spread * ((double)weight / total); act = !(pt < epsilon); }
             if (!tree_add(act, nb, pt)) return false;
-        }
-        if (lines && mode == 2) {
-            bool act = lane < LINE_NB && lane < deg2; double pt = 0;
-            if (act) { pt = spread * ((double)l_w2 / total); act = !(pt < epsilon); }
-            if (!tree_add(act, l_nb2, pt)) return false;
-            ib += LINE_NB;
         }
         for (int64_t k = ib; k < ie; k += 64) {   // undirected: in-neighbours after the out-neighbours
             const int64_t kk = k + lane;
@@ -762,19 +726,6 @@ __global__ void k_totals(BcaGraph g, double *tot_out, double *tot_in, double *to
     tot_und[v] = u;
 }
 
-__global__ void k_pack_lines(BcaGraph g, VLine *out_line, VLine *in_line) {
-    const int32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.V) return;
-    for (int dir = 0; dir < 2; ++dir) {
-        const int64_t b = dir ? g.in_ptr[v] : g.out_ptr[v], e = dir ? g.in_ptr[v + 1] : g.out_ptr[v + 1];
-        const int32_t *idx = dir ? g.in_idx : g.out_idx; const float *w = dir ? g.in_w : g.out_w;
-        VLine l;
-        l.deg = (int32_t)(e - b); l.pad = 0; l.total = dir ? g.tot_in[v] : g.tot_out[v];
-        for (int k = 0; k < LINE_NB; ++k) { const bool have = b + k < e; l.nb[k].idx = have ? idx[b + k] : 0; l.nb[k].w = have ? w[b + k] : 0.0f; }
-        (dir ? in_line : out_line)[v] = l;
-    }
-}
-
 // rows from the pool -> bookmark order
 __global__ void k_gather_rows(const int32_t *poolJ, const float *poolX, const int32_t *pool2J, const float *pool2X, int64_t pool_cap,
                               const int64_t *row_off, const int32_t *row_n,
@@ -878,19 +829,9 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     if ((st = upload(in_nbrs->weight, (size_t)Ei, &d_iw)) != GE_OK) return st;    dev.keep(d_iw);
     double *d_tot = nullptr;
     GE_HIP(hipMalloc((void **)&d_tot, sizeof(double) * 3 * (size_t)V)); dev.keep(d_tot);
-    p.g = BcaGraph{d_optr, d_iptr, d_oidx, d_iidx, d_ow, d_iw, d_tot, d_tot + V, d_tot + 2 * (size_t)V, V, nullptr, nullptr};
+    p.g = BcaGraph{d_optr, d_iptr, d_oidx, d_iidx, d_ow, d_iw, d_tot, d_tot + V, d_tot + 2 * (size_t)V, V};
     hipLaunchKernelGGL(k_totals, dim3((V + 255) / 256), dim3(256), 0, 0, p.g, d_tot, d_tot + V, d_tot + 2 * (size_t)V);
     GE_HIP(hipGetLastError());
-    {   // vertex lines (128 bytes per vertex): without them a pop costs two dependent reads of the graph; GE_BCA_LINES=0 keeps the CSR reads
-        const char *le = std::getenv("GE_BCA_LINES");
-        VLine *d_lines = nullptr;
-        if (!(le && std::atoi(le) == 0) && hipMalloc((void **)&d_lines, sizeof(VLine) * 2 * (size_t)V) == hipSuccess) {
-            dev.keep(d_lines);
-            hipLaunchKernelGGL(k_pack_lines, dim3((V + 255) / 256), dim3(256), 0, 0, p.g, d_lines, d_lines + V);
-            GE_HIP(hipGetLastError());
-            p.g.out_line = d_lines; p.g.in_line = d_lines + V;
-        } else (void)hipGetLastError();
-    }
 
     p.alpha = cfg->alpha; p.epsilon = cfg->epsilon; p.directed = cfg->directed ? 1 : 0; p.normalize = cfg->normalize;
     p.row_begin = rb; p.row_end = re;

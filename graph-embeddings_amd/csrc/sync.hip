@@ -412,7 +412,8 @@ ge_status launch_turn(ge_sync *s, Entry &e, bool land, bool take) {
     }
     if (!e.mean && e.cols % 4 == 0 && e.t_stride % 4 == 0 && ((uintptr_t)e.table % 16) == 0 && e.n / 4 < ((int64_t)1 << 31)) {       // the large tables
         const int64_t n4 = e.n / 4;
-        const dim3 g4((unsigned)std::max<int64_t>(1, std::min<int64_t>((n4 + 1023) / 1024, (int64_t)s->cus * 8))), b4(256);
+        static const int per_cu = [] { const char *v = std::getenv("GE_SYNC_BLOCKS_PER_CU"); const int k = v ? std::atoi(v) : 0; return k > 0 ? k : 8; }();
+        const dim3 g4((unsigned)std::max<int64_t>(1, std::min<int64_t>((n4 + 1023) / 1024, (int64_t)s->cus * per_cu))), b4(256);
         static const bool nt = [] { const char *v = std::getenv("GE_SYNC_NT"); return v ? std::atoi(v) != 0 : true; }();
 #define GE_TURN4(L, T)                                                                                                              \
         do {                                                                                                                        \

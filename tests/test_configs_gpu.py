@@ -8,6 +8,8 @@ C3' DBLP-like graph (a stand-in: the DBLP data is not in the reference) through 
 Lost runs: no focus row is resident in two workers at once -- measured, and shown to be what the
     round-1 layout (layout: fixed_cuts) loses.
 The oracle is single-threaded here; these are the slow tests of the suite (about a minute in all)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -21,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 def test_c2_full_size_cost_trajectory(gpu):
     """BASELINE C2.  Per-epoch mean cost, device (thousands of racing workers, blocked order) / sequential oracle
-    (Java order, same seed): within 10 % in the first two epochs (the blocked order alone shifts them), within 4 % after."""
+    (Java order, same seed), TEN epochs: within 10 % in the first two (the blocked order alone shifts them), within 4 % after."""
     V, D = 100_000, 100
     I, J, X, xmax = synth.synthetic_coo_shard(V, (0, V), 12_100_000, seed=0xC0FFEE)     # the generator drops duplicate (i, j): 10.0 M remain
     n = len(I)
@@ -30,13 +32,20 @@ def test_c2_full_size_cost_trajectory(gpu):
     opt = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
     info = opt.info()
     assert info["groups_in_flight"] >= 1024 and info["long_rows"] >= 0
-    dev = np.array([opt.epoch(it) / n for it in range(5)])
+    EP = 10
+    dev = np.array([opt.epoch(it) / n for it in range(EP)])
+    # the sequential oracle's trajectory on this matrix and seed is a committed fixture (tests/golden/c2_oracle_costs.npz, written by
+    # tools/r03/convergence.py's oracle leg: 20 s per epoch on one core); its first two epochs are recomputed here to tie the file to the code
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_oracle_costs.npz"))
+    assert int(gold["nnz"]) == n and int(gold["V"]) == V and int(gold["D"]) == D
     ora = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
-    ref = np.array([ora.epoch() for _ in range(5)])
+    live = np.array([ora.epoch() for _ in range(2)])
+    np.testing.assert_array_equal(live, gold["costs"][:2])
+    ref = gold["costs"][:EP]
     print("C2 device/oracle per epoch:", np.round(dev / ref, 4).tolist(), "workers", info["groups_in_flight"])
-    assert np.all(np.isfinite(dev)) and dev[-1] < dev[0]
+    assert np.all(np.isfinite(dev)) and np.all(np.diff(dev) < 0)
     np.testing.assert_allclose(dev[:2], ref[:2], rtol=0.10)
-    np.testing.assert_allclose(dev[2:], ref[2:], rtol=0.04)
+    np.testing.assert_allclose(dev[2:], ref[2:], rtol=0.04)       # the lag grows to 6.8 % by epoch 27 and holds there
 
 
 def _cos_matrix(E):
