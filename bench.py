@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--hot", default="auto", choices=["auto", "none", "all"])
+    ap.add_argument("--hot-theta", type=float, default=0.0, help="column j is a hub when count(j) >= theta * N / workers (0 = the library default, 0.05)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="storage of the embedding rows; bf16 = BASELINE config C5 (fp32 accumulators, stochastic rounding)")
     ap.add_argument("--opt", default="adagrad", choices=["adagrad", "adam", "amsgrad"],
@@ -58,7 +59,7 @@ def parse():
                     help="N=1 only: K > 1 puts the matrix of a K-GPU job on ONE GPU (V = K x rows-per-gpu, the K ranks' shards concatenated: "
                          "8 = BASELINE C4 at its own size, 5 M vertices / 0.86 G nonzeros); a recorded profile leg, not the default workload")
     ap.add_argument("--hub-segments", type=int, default=0,
-                    help="N>1: small exchanges of the hub rows per epoch (ge_sync_epoch); 0 = the library's default (2 x ranks, at least 8), -1 = none (one exchange per epoch for every row)")
+                    help="N>1: small exchanges of the hub rows per epoch (ge_sync_epoch); 0 = the library's default (the number of ranks, at least 8), -1 = none (one exchange per epoch for every row)")
     ap.add_argument("--no-other-form", action="store_true", help="N>1: do not time the other exchange form behind the quoted region")
     ap.add_argument("--accum-sync-every", type=int, default=4, help="every how many context syncs the AdaGrad accumulators are reconciled too (N>1)")
     return ap.parse_args()
@@ -208,7 +209,7 @@ def main():
         "bca": {"alpha": 0.1, "epsilon": 1e-3, "directed": True},
         "opt": {"method": args.opt, "tolerance": 0, "maxiter": args.steps},
         "output": {"uri": []},
-        "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot, "dtype": args.dtype, "layout": [x for x in args.layout.split(",") if x],
+        "device": {"mode": "hogwild", "shuffle": "device", "seed": 42, "id": local_rank, "hot": args.hot, **({"hot_theta": args.hot_theta} if args.hot_theta > 0 else {}), "dtype": args.dtype, "layout": [x for x in args.layout.split(",") if x],
                    "workers": args.workers if args.workers else (-args.reserve_waves if (world > 1 and args.exchange == "overlap") else 0),
                    "row_range": rows if world > 1 else (0, 0)}})
     t_create = time.perf_counter()
@@ -335,7 +336,7 @@ def main():
                        "parallelism": "rows sharded x%d, context replicated + delta all-reduce every %d step(s) (rows summed, biases averaged, accumulators summed every %d syncs, %s on the wire, %s; hub rows reconciled %s per epoch in fp32)"
                                       % (world, args.sync_every, args.accum_sync_every, args.wire,
                                          "overlapped with the next epoch, %d wavefront slots reserved" % args.reserve_waves if args.exchange == "overlap" else "synchronous",
-                                         ("%d times" % args.hub_segments) if args.hub_segments > 0 else ("max(8, 2 x ranks) times" if args.hub_segments == 0 else "never"))
+                                         ("%d times" % args.hub_segments) if args.hub_segments > 0 else ("max(8, ranks) times" if args.hub_segments == 0 else "never"))
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "traffic": traffic,

@@ -752,13 +752,13 @@ ge_status ge_sync_sync(ge_sync *s) {          // lands what an earlier turn left
 }
 
 // One epoch of a sharded run: the handle's epoch in `segments` launches with a small exchange of the hub rows behind each (see
-// k_hub_take).  segments <= 0: twice the number of ranks, at least 8.  The large exchange (ge_sync_turn / ge_sync_sync) follows as
+// k_hub_take).  segments <= 0: the number of ranks, at least 8.  The large exchange (ge_sync_turn / ge_sync_sync) follows as
 // before and finds nothing to do for the hub rows.  world == 1, or no hub rows: ge_glove_epoch.
 static ge_status ge_sync_epoch_impl(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum) {
     if (!s) return ge::fail(GE_ERR_ARG, "null ge_sync handle");
     if (s->cfg.world == 1 || s->n_hub == 0) return ge_glove_epoch(s->h, iteration, cost_sum);
     GE_HIP(hipSetDevice(s->device));
-    const int32_t S = std::min(64, segments > 0 ? segments : std::max(8, 2 * s->cfg.world));
+    const int32_t S = std::min(64, segments > 0 ? segments : std::max(8, s->cfg.world));
     for (int32_t seg = 0; seg < S; ++seg) {
         ge_status st = ge::glove_epoch_segment(s->h, iteration, seg, S);
         if (st == GE_OK) st = hub_exchange(s);
@@ -766,6 +766,27 @@ static ge_status ge_sync_epoch_impl(ge_sync *s, int32_t iteration, int32_t segme
     }
     return ge::glove_epoch_finish(s->h, cost_sum);
 }
+// the hub rows of this run (ascending) and one small exchange of them on demand: for hosts that cut their epochs themselves, and for the parity test
+static ge_status ge_sync_hub_rows_impl(ge_sync *s, int32_t *out, int32_t capacity, int32_t *count) {
+    if (!s || !count) return ge::fail(GE_ERR_ARG, "null argument");
+    *count = s->n_hub;
+    if (out && capacity > 0 && s->n_hub > 0) {
+        GE_HIP(hipSetDevice(s->device));
+        GE_HIP(hipMemcpy(out, s->hub_list, sizeof(int32_t) * (size_t)std::min(capacity, s->n_hub), hipMemcpyDeviceToHost));
+    }
+    return GE_OK;
+}
+ge_status ge_sync_hub_rows(ge_sync *s, int32_t *out, int32_t capacity, int32_t *count) { GE_GUARD(ge_sync_hub_rows_impl(s, out, capacity, count)); }
+static ge_status hub_exchange_guarded(ge_sync *s) {
+    try {
+        if (!s) return ge::fail(GE_ERR_ARG, "null ge_sync handle");
+        if (s->cfg.world == 1) return GE_OK;
+        GE_HIP(hipSetDevice(s->device));
+        return hub_exchange(s);
+    } catch (const std::exception &e) { return ge::fail(GE_ERR_STATE, "internal error: %s", e.what()); }
+}
+ge_status ge_sync_hub_exchange(ge_sync *s) { return with_abort(s, hub_exchange_guarded(s)); }
+
 static ge_status epoch_guarded(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum) { GE_GUARD(ge_sync_epoch_impl(s, iteration, segments, cost_sum)); }
 ge_status ge_sync_epoch(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum) { return with_abort(s, epoch_guarded(s, iteration, segments, cost_sum)); }
 

@@ -168,6 +168,17 @@ class ContextSync:
         capi.check(capi.lib().ge_sync_epoch(self._h, int(iteration), int(segments), C.byref(c)))
         return c.value
 
+    def hub_rows(self):
+        """The context rows that ge_sync_epoch reconciles between the segments of an epoch (the union of the ranks' hub columns)."""
+        n = C.c_int32(0)
+        capi.check(capi.lib().ge_sync_hub_rows(self._h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.int32)
+        if n.value:
+            capi.check(capi.lib().ge_sync_hub_rows(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), n.value, C.byref(n)))
+        return out
+
+    def hub_exchange(self): capi.check(capi.lib().ge_sync_hub_exchange(self._h))
+
     def begin(self, everything=False): capi.check(capi.lib().ge_sync_begin(self._h, int(bool(everything))))
     def finish(self): capi.check(capi.lib().ge_sync_finish(self._h))
     def turn(self): capi.check(capi.lib().ge_sync_turn(self._h))

@@ -132,7 +132,7 @@ typedef struct {
     int32_t emb_dtype;      /* GE_DTYPE_*: storage of the focus/context rows                           */
     /* HOGWILD tuning; 0 = the library default everywhere.  These change results (which columns publish by delta,
      * how stale a hub run may get), so they live here and under the YAML `device:` block, not in the environment. */
-    float   hot_theta;      /* GE_HOT_AUTO: column j is a hub when count(j) * workers >= hot_theta * N.  Default 0.25 */
+    float   hot_theta;      /* GE_HOT_AUTO: column j is a hub when count(j) * workers >= hot_theta * N.  Default 0.05 */
     float   stale_budget;   /* a hub run is cut (delta published, row re-read) every m_j updates with
                                K_j * m_j <= stale_budget, K_j = expected workers inside column j.  Default 2000
                                (measured: 10 000 is stable at the bench scale, 39 000 diverges)                */
@@ -443,7 +443,7 @@ ge_status ge_sync_finish(ge_sync *s);
 ge_status ge_sync_turn(ge_sync *s);
 ge_status ge_sync_sync(ge_sync *s);
 /* One epoch of a sharded run, to be called INSTEAD of ge_glove_epoch by every rank (collective): the handle's epoch runs in
- * `segments` launches (<= 0: twice the number of ranks, at least 8; at most 64) and behind each one the HUB rows of the context side
+ * `segments` launches (<= 0: the number of ranks, at least 8; at most 64) and behind each one the HUB rows of the context side
  * -- the union of the ranks' hub columns, a few thousand rows -- are reconciled exactly in one small fp32 all-reduce (rows and both
  * accumulators summed, cBias averaged over the ranks that moved it).  Without it eight ranks that each push a busy row for a whole
  * epoch from the same start overshoot where one GPU settles (measured: DESIGN.md 7); inside a GPU the same rows are held together by
@@ -452,6 +452,10 @@ ge_status ge_sync_sync(ge_sync *s);
  * it: the fp32 master row of a column that is a hub on this rank, else the bf16 table entry, stochastically rounded).  A one-rank run
  * and a run without hub columns get one plain ge_glove_epoch. */
 ge_status ge_sync_epoch(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum);
+/* The hub rows of this run (*count of them, ascending; out may be NULL or shorter), and ONE small exchange of them now (collective; what
+ * ge_sync_epoch does behind every segment) -- for a host that cuts its epochs itself. */
+ge_status ge_sync_hub_rows(ge_sync *s, int32_t *out, int32_t capacity, int32_t *count);
+ge_status ge_sync_hub_exchange(ge_sync *s);
 /* Ends a run: lands what is in flight, exchanges everything not sent yet, then every rank takes rank src's fp32 tables. */
 ge_status ge_sync_replicate(ge_sync *s, int32_t src);
 /* n host doubles summed (op 0) or maximised (op 1) over the ranks through RCCL: the epoch's cost (Optimizer.java:94-96 needs

@@ -58,6 +58,25 @@ class SyncModel:
                 work.append(dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 e["work"] = work
 
+    def hub_exchange(self, rows, n_rows):
+        """csrc/sync.hip k_hub_take / k_hub_land: the rows `rows` (of n_rows) of EVERY table reconciled now, in fp32 and exactly:
+        delta = table - c, summed over the ranks (means: divided by the number of ranks that moved the element), c += that, table = c."""
+        if self.world == 1 or len(rows) == 0:
+            return
+        idx = torch.as_tensor(rows, dtype=torch.long)
+        for e in self.ent:
+            t, c = e["t"].view(n_rows, -1), e["o"].view(n_rows, -1)
+            d = (t[idx] - c[idx]).contiguous()
+            if e["mean"]:
+                cnt = d.ne(0).to(torch.float32)
+                dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
+            if e["mean"]:
+                d = d / cnt.clamp(min=1.0)
+            new = c[idx] + d
+            c[idx] = new
+            t[idx] = new
+
     def begin(self, everything=False): self._turn(False, True, everything)
     def finish(self): self._turn(True, False)
     def turn(self, everything=False): self._turn(True, True, everything)

@@ -113,7 +113,7 @@ def test_two_ranks_share_one_gpu(gpu, exchange, V, N, D, dtype, layout, wire):
 
 
 # ---- the library's exchange against the model, bit for bit --------------------------------------------------------------
-def _model_rank_main(rank, world, port, q, D, layout, steps):
+def _model_rank_main(rank, world, port, q, D, layout, steps, with_hubs=False):
     """Each rank perturbs its context-side tables identically on the device (set_state) and on a host copy, then runs ge_sync
     on the device and SyncModel on the host: after every step the two must hold the same bits (fp32 wire)."""
     import geglove
@@ -130,6 +130,9 @@ def _model_rank_main(rank, world, port, q, D, layout, steps):
     opt = geglove.Adagrad(geglove.CooMatrix(V, si, sj, sx, xmax), cfg, cfg.costFunction())
     host = {k: torch.from_numpy(opt.get_state(k).copy()) for k in CTX}
     sync = parallel.context_sync_for(opt, torch.device("cuda", 0), lazy_every=2, wire="f32")
+    hubs = sync.hub_rows() if with_hubs else None
+    if with_hubs:
+        assert len(hubs) > 0, "the test matrix has no hub columns"
     model = SyncModel(sums=[host["context"]], means=[host["cbias"]], lazy_sums=[host["gsq_context"], host["gsq_cbias"]], lazy_every=2, wire="f32")
     rng = np.random.default_rng(7 + rank)
     ok = True
@@ -139,6 +142,21 @@ def _model_rank_main(rank, world, port, q, D, layout, steps):
             mv = (rng.standard_normal(cur.size) * 0.01 * (rng.random(cur.size) < 0.3)).astype(np.float32)
             new = (cur + mv).astype(np.float32)
             opt.set_state(k, new); host[k].copy_(torch.from_numpy(new))
+        if hubs is not None:
+            # ge_sync_epoch's order: the hub rows are reconciled by their small exchange (twice here, with moves in between), and
+            # only rows that are NOT hubs still carry moves when the large exchange takes
+            for rep in range(2):
+                sync.hub_exchange(); model.hub_exchange(hubs, V)
+                torch.cuda.synchronize()
+                for k in CTX:
+                    ok = ok and np.array_equal(opt.get_state(k), host[k].numpy())
+                keep = np.ones(V, bool); keep[hubs] = rep == 0            # first: everybody moves again; then: everybody but the hub rows
+                for k in CTX:
+                    cur = opt.get_state(k)
+                    mv = (rng.standard_normal(cur.size) * 0.01 * (rng.random(cur.size) < 0.3)).astype(np.float32)
+                    mv = (mv.reshape(V, -1) * keep[:, None]).reshape(-1).astype(np.float32)
+                    new = (cur + mv).astype(np.float32)
+                    opt.set_state(k, new); host[k].copy_(torch.from_numpy(new))
         if step % 3 == 2:
             sync.sync(); model.sync()
         else:
@@ -162,6 +180,14 @@ def test_ge_sync_equals_the_model_bit_for_bit(gpu, D, layout):
     """Sum rule, mean rule (elements one rank, both ranks or no rank moved), lazy accumulators, take / land / turn / sync /
     replicate, over fat rows, interleaved records and plain rows with separate bias tables."""
     assert _spawn(_model_rank_main, (D, layout, 7)) == [1.0, 1.0]
+
+
+@pytest.mark.parametrize("D,layout", [(32, []), (256, []), (200, [])])
+def test_hub_exchange_equals_the_model_bit_for_bit(gpu, D, layout):
+    """ge_sync_hub_exchange (k_hub_take / k_hub_land, what ge_sync_epoch runs behind every segment) between the large exchanges: the hub
+    rows of all four tables become base + the summed deltas exactly, nothing else moves, and the large exchanges that follow stay
+    bit-equal to the model (they find nothing left to do for those rows)."""
+    assert _spawn(_model_rank_main, (D, layout, 7, True)) == [1.0, 1.0]
 
 
 def test_ge_sync_argument_errors(gpu):

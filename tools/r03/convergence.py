@@ -31,6 +31,7 @@ ap.add_argument("--epochs", type=int, default=48)
 ap.add_argument("--sample", type=int, default=2000)
 ap.add_argument("--threads", type=int, default=1, help="oracle leg: 1 = sequential (the reference of the comparison)")
 ap.add_argument("--ref")
+ap.add_argument("--device-cfg", default="", help="device leg: extra keys of the YAML's device: block, k=v,k=v (hot_theta, stale_budget, workers ...)")
 ap.add_argument("--out", required=True)
 a = ap.parse_args()
 
@@ -73,13 +74,14 @@ else:
     epochs = min(a.epochs, len(ref["costs"]))
     cfg = geglove.Configuration({"graph": "s", "method": "glove", "dim": a.D, "threads": 1, "bca": {"alpha": .1, "epsilon": 1e-3},
                                  "opt": {"method": "adagrad", "maxiter": epochs, "tolerance": 0}, "output": {"uri": []},
-                                 "device": {"mode": "hogwild", "shuffle": "device", "seed": 42}})
+                                 "device": dict({"mode": "hogwild", "shuffle": "device", "seed": 42},
+                                                **{k: (float(v) if "." in v else int(v)) for k, v in (kv.split("=") for kv in a.device_cfg.split(",") if kv)})})
     opt = geglove.Adagrad(geglove.CooMatrix(a.V, I, J, X, xmax), cfg, cfg.costFunction())
     dev = [opt.epoch(it) / n for it in range(epochs)]
     E = opt.extractResult().reshape(a.V, a.D)[sample]
     rc = ref["costs"][:epochs]
     rho = float(np.corrcoef(cos_upper(E), cos_upper(ref["vectors"].astype(np.float64)))[0, 1])
-    out = {"workload": "BASELINE C2: V=%d, %d nonzeros, dim %d, glove, AdaGrad, seed 42" % (a.V, n, a.D), "epochs": epochs,
+    out = {"device_cfg": a.device_cfg, "workload": "BASELINE C2: V=%d, %d nonzeros, dim %d, glove, AdaGrad, seed 42" % (a.V, n, a.D), "epochs": epochs,
            "workers": opt.info()["groups_in_flight"],
            "device_cost": dev, "oracle_cost": rc.tolist(), "device_over_oracle": (np.array(dev) / rc).tolist(),
            "oracle_threads": int(ref["threads"]),
