@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--hot", default="auto", choices=["auto", "none", "all"])
-    ap.add_argument("--hot-theta", type=float, default=0.0, help="column j is a hub when count(j) >= theta * N / workers (0 = the library default, 0.05)")
+    ap.add_argument("--hot-theta", type=float, default=0.0, help="column j is a hub when count(j) >= theta * N / workers (0 = the library default, 0.25)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="storage of the embedding rows; bf16 = BASELINE config C5 (fp32 accumulators, stochastic rounding)")
     ap.add_argument("--opt", default="adagrad", choices=["adagrad", "adam", "amsgrad"],

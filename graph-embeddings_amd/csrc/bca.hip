@@ -82,6 +82,7 @@ struct BcaParams {
     int64_t out_cap;
     unsigned long long *pool_used;     // bump allocator
     unsigned long long *queue;         // next bookmark
+    unsigned long long *prof;          // GE_BCA_TIMING: [0] shader-clock ticks spent in the passes, [1] in the emission, summed over the wavefronts (else null)
     int32_t *status;                   // 0 ok, 1 table overflow, 2 active-list overflow, 3 pool overflow
     const int32_t *redo;               // second launch: the bookmarks (relative to row_begin) whose rows did not fit
     int32_t n_jobs;                    // number of jobs in this launch (all rows, or the redo list)
@@ -401,14 +402,16 @@ __device__ __forceinline__ int float_compare(float a, float b) {
 // reaches 8 (merge() treeifies with the 8th node, putVal with the 9th; 8 covers both).  Until that first event the
 // load-factor trajectory IS the map's trajectory, so "no level reaches 8" is exact, not a heuristic; a row that does
 // is replayed sequentially (ge_jhashmap_dev.h).  O(n) per row.  Wave-uniform result.
-template <class IDX>
+// LOCAL: the histogram (w.jhead) lives in LDS, so the two fences per level need not wait for global stores in flight.
+template <bool LOCAL, class IDX>
 __device__ bool bins_may_treeify(const BcaParams &p, const BcaWork &w, int32_t n_touched, int32_t n_total, IDX idx) {
     const int lane = threadIdx.x & 63;
     bool flag = false;
+    auto sync = [] { if constexpr (LOCAL) wave_sync_lds(); else wave_sync(); };
     for (int32_t c = 16; n_total >= 8; c <<= 1) {
         const int32_t thr = (c / 4) * 3;
         for (int i = lane; i < c; i += 64) w.jhead[i] = 0;
-        wave_sync();
+        sync();
         for (int e = lane; e < n_touched; e += 64) {
             const int32_t k = idx(e);
             if (k >= 0 && k <= thr) {
@@ -416,7 +419,7 @@ __device__ bool bins_may_treeify(const BcaParams &p, const BcaWork &w, int32_t n
                 flag |= __hip_atomic_fetch_add(w.jhead + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) + 1 >= 8;
             }
         }
-        wave_sync();
+        sync();
         if (__ballot(flag) != 0 || n_total - 1 <= thr || c >= p.hc) break;
     }
     return __ballot(flag) != 0;
@@ -435,12 +438,21 @@ template <bool LDS>
 __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x;
-    const BcaWork w = carve(p, wave);
-    __shared__ double s_paint[LDS ? LDS_HC : 1];
-    __shared__ int32_t s_hkey[LDS ? LDS_HC : 1];
-    __shared__ float s_val[LDS ? LDS_HC : 1];
-    __shared__ int32_t s_alist[LDS ? LDS_AC : 1];
-    __shared__ int16_t s_seq[LDS ? LDS_HC : 1];
+    BcaWork w = carve(p, wave);
+    // LDS, two views of one buffer: during the passes the hot table of the bookmark (paint 6 144 B | keys 3 072 | BCV values 3 072 |
+    // sequences 1 536 | active list 1 536); during the emission -- the passes' result has been handed to the global workspace by then --
+    // the sort keys of the row (4 096 B), the bin histogram / bin heads of the exact replay (4 096) and the row itself in iteration
+    // order (values 2 048, keys 2 048), so that ranking, the treeify check and the sequential folds of the normalisation run on LDS.
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS ? 15360 : 16];
+    double *const s_paint = reinterpret_cast<double *>(s_raw);
+    int32_t *const s_hkey = reinterpret_cast<int32_t *>(s_raw + (LDS ? 6144 : 0));
+    float *const s_val = reinterpret_cast<float *>(s_raw + (LDS ? 9216 : 0));
+    int16_t *const s_seq = reinterpret_cast<int16_t *>(s_raw + (LDS ? 12288 : 0));
+    int32_t *const s_alist = reinterpret_cast<int32_t *>(s_raw + (LDS ? 13824 : 0));
+    float *const e_x = reinterpret_cast<float *>(s_raw + (LDS ? 8192 : 0));
+    int32_t *const e_j = reinterpret_cast<int32_t *>(s_raw + (LDS ? 10240 : 0));
+    static_assert(LDS_HC == 768 && LDS_AC == 384 && LDS_MAX == 512, "the two LDS views are laid out for these sizes");
+    if constexpr (LDS) { w.okey = reinterpret_cast<unsigned long long *>(s_raw); w.jhead = reinterpret_cast<int32_t *>(s_raw + 4096); }
     const BcaHot hot{s_hkey, s_paint, s_val, s_seq, s_alist, w.touched};
     // table starts empty
     if constexpr (LDS) { for (int i = lane; i < LDS_HC; i += 64) s_hkey[i] = KEY_EMPTY; }
@@ -452,6 +464,7 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
         const int32_t job = rfl((int)ticket);
         if (job >= p.n_jobs || ticket >= (unsigned long long)p.n_jobs) break;
         const int32_t r = p.redo ? p.redo[job] : job;
+        const unsigned long long t_start = p.prof ? __builtin_amdgcn_s_memtime() : 0ull;
         const int32_t bookmark = p.row_begin + r;
         int32_t n_touched = 0, nf = 0, nr = 0;
         int32_t status = 0;
@@ -485,6 +498,7 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
             if (ok && p.directed) ok = bca_pass(p, w, bookmark, 1, true, n_touched, nr, &status);   // DirectedWeighted: reverse = true always
         }
         status = rfl(status);
+        const unsigned long long t_passes = p.prof ? __builtin_amdgcn_s_memtime() : 0ull;
         if (LDS && !ok && status == 4) {                   // outgrew the LDS tables: the global-memory kernel runs this bookmark
             if (lane == 0) { p.row_n[r] = 0; p.row_off[r] = -2; p.row_max[r] = 1.0f; atomicMax(p.status, 4); }
             for (int i = lane; i < LDS_HC; i += 64) s_hkey[i] = KEY_EMPTY;
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
             bool exact_overflow = false;
             if (p.directed) {
                 const int32_t cap_r = java_cap_after_puts(nr);
-                const bool rev_exact = bins_may_treeify(p, w, n_touched, nr, [&](int e) { return w.rseq[w.touched[e]]; });
+                const bool rev_exact = bins_may_treeify<LDS>(p, w, n_touched, nr, [&](int e) { return w.rseq[w.touched[e]]; });
                 if (rev_exact) {
                     // the reverse BCV is a map built by putVal alone; replay it and walk its bins
                     if (lane == 0) {
@@ -596,7 +610,7 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
             // sequence, then BCV.merge over the reverse BCV's iteration order, then -- normalised rows --
             // remove(rootNode), which in a tree bin is not a plain unlink.  okey becomes the key's iteration position;
             // the root of a normalised row is ranked first, where the code below finds and drops it.
-            const bool fwd_exact = !exact_overflow && bins_may_treeify(p, w, n_touched, n_out, [&](int e) {
+            const bool fwd_exact = !exact_overflow && bins_may_treeify<LDS>(p, w, n_touched, n_out, [&](int e) {
                 const int32_t fs = w.fseq[w.touched[e]];
                 return fs >= 0 ? fs : (fs <= -2 ? nf + (-fs - 2) : -1);
             });
@@ -634,12 +648,62 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
             if (off + n_out > p.out_cap) { fits = false; }      // the row size is known: it is re-run alone into an exact pool
             if (!fits) {
                 if (lane == 0) { p.row_n[r] = n_out; p.row_off[r] = -1; p.row_max[r] = 1.0f; atomicMax(p.status, 3); }
-                if constexpr (LDS) { for (int e = lane; e < n_touched; e += 64) s_hkey[w.touched[e]] = KEY_EMPTY; }
+                if constexpr (LDS) { for (int i = lane; i < LDS_HC; i += 64) s_hkey[i] = KEY_EMPTY; }       // (the emission has used the LDS)
                 else { for (int e = lane; e < n_touched && e < p.hc / 2; e += 64) w.hkey[w.touched[e]] = KEY_EMPTY; }
                 wave_sync();
                 continue;
             }
-            if (ok) {
+            if (ok && LDS) {
+                // the row in iteration order, in LDS
+                for (int e = lane; e < n_cand; e += 64) {
+                    const unsigned long long me = w.okey[e];
+                    if (me == ~0ull) continue;
+                    int32_t rank = 0;
+                    for (int o = 0; o < n_cand; ++o) rank += w.okey[o] < me;
+                    const int32_t s = w.touched[e];
+                    e_j[rank] = w.hkey[s];
+                    e_x[rank] = w.fval[s];
+                }
+                wave_sync_lds();
+                int32_t n = n_out;
+                if (p.normalize != GE_NORM_NONE) {
+                    // BCV.toCounts / remove(rootNode) / toUnity: sequential float folds in iteration order, by one lane, on LDS
+                    if (lane == 0) {
+                        if (p.normalize == GE_NORM_COUNTS) {
+                            float aMax = 1.0f, aMin = 0.0f;
+                            for (int k = 0; k < n; ++k) {
+                                const float v = e_x[k];
+                                if (k == 0) { aMax = v; aMin = v; }
+                                else { aMax = float_compare(aMax, v) >= 0 ? aMax : v; aMin = float_compare(aMin, v) <= 0 ? aMin : v; }
+                            }
+                            for (int k = 0; k < n; ++k) e_x[k] = (e_x[k] / ((aMax - aMin) / (1000.0f - 1.0f))) + 1.0f;
+                        }
+                        int k = 0;
+                        while (k < n && e_j[k] != bookmark) ++k;                   // remove(rootNode)
+                        for (int q = k; q + 1 < n; ++q) { e_j[q] = e_j[q + 1]; e_x[q] = e_x[q + 1]; }
+                        if (k < n) --n;
+                        if (p.normalize == GE_NORM_UNITY) {
+                            float sum = 0.0f;
+                            for (int q = 0; q < n; ++q) sum = q == 0 ? e_x[q] : sum + e_x[q];      // reduce(Float::sum)
+                            for (int q = 0; q < n; ++q) e_x[q] = e_x[q] / sum - 1e-6f;
+                        }
+                    }
+                    wave_sync_lds();
+                    n = rfl(n);
+                }
+                // BCV.max(): the maximum under Float.compare is a total-order maximum -- any association gives the sequential fold's result
+                float mx = 0.0f; bool have = false;
+                for (int k = lane; k < n; k += 64) { const float v = e_x[k]; mx = !have ? v : (float_compare(mx, v) >= 0 ? mx : v); have = true; }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) {
+                    const float o = __shfl_xor(mx, m, 64); const int oh = __shfl_xor((int)have, m, 64);
+                    if (oh) { mx = !have ? o : (float_compare(mx, o) >= 0 ? mx : o); have = true; }
+                }
+                row_max = have ? mx : 1.0f;                                   // max().orElse(1f)
+                for (int k = lane; k < n; k += 64) { p.outJ[off + k] = e_j[k]; p.outX[off + k] = e_x[k]; }
+                n_out = n;
+            }
+            if (ok && !LDS) {
                 for (int e = lane; e < n_cand; e += 64) {
                     const unsigned long long me = w.okey[e];
                     if (me == ~0ull) continue;
@@ -701,8 +765,12 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
             p.row_max[r] = row_max;
             if (!ok) atomicMax(p.status, LDS ? 4 : (status ? status : 1));
         }
+        if (p.prof && lane == 0) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            atomicAdd(p.prof, t_passes - t_start); atomicAdd(p.prof + 1, t_end - t_passes);
+        }
         // reset the table for the next bookmark
-        if constexpr (LDS) { for (int e = lane; e < n_touched && e < LDS_MAX; e += 64) s_hkey[w.touched[e]] = KEY_EMPTY; }
+        if constexpr (LDS) { for (int i = lane; i < LDS_HC; i += 64) s_hkey[i] = KEY_EMPTY; }       // (the emission has used the LDS)
         else {
             for (int e = lane; e < n_touched && e < p.hc / 2; e += 64) w.hkey[w.touched[e]] = KEY_EMPTY;
             if (!ok && status == 1) for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY;   // touched[] was truncated
@@ -849,6 +917,9 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     GE_HIP(hipMalloc((void **)&d_ctr, 32)); dev.keep(d_ctr);
     p.row_n = d_row_n; p.row_off = d_row_off; p.row_max = d_row_max;
     p.pool_used = d_ctr; p.queue = d_ctr + 1; p.status = reinterpret_cast<int32_t *>(d_ctr + 2);
+    unsigned long long *d_prof = nullptr;
+    if (clk.on) { GE_HIP(hipMalloc((void **)&d_prof, 16)); dev.keep(d_prof); GE_HIP(hipMemset(d_prof, 0, 16)); }
+    p.prof = d_prof;
 
     // ---- the passes ---------------------------------------------------------------------------------------------------------
     // Main launch: the LDS kernel (k_bca<true>: 1 024-slot tables per wavefront in LDS, seven wavefronts per CU) over every
@@ -945,6 +1016,12 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
         break;
     }
     dev.keep(d_pJ); dev.keep(d_pX);
+    if (d_prof) {
+        unsigned long long hp[2] = {0, 0};
+        GE_HIP(hipMemcpy(hp, d_prof, 16, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "[ge_bca_build] wavefront time in the passes %.1f %%, in the emission %.1f %% (%.3g / %.3g ticks)\n",
+                     100.0 * (double)hp[0] / (double)std::max<unsigned long long>(hp[0] + hp[1], 1), 100.0 * (double)hp[1] / (double)std::max<unsigned long long>(hp[0] + hp[1], 1), (double)hp[0], (double)hp[1]);
+    }
     if (status != 0) {
         // rows left over: no room in the pool (row_off -1, size in row_n) or too large for the LDS tables (row_off -2, size unknown)
         GE_HIP(hipMemcpy(h_n.data(), d_row_n, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost));

@@ -1315,9 +1315,10 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
             h->hw_blocks = (int)std::max<int64_t>(1, (int64_t)h->hw_blocks - (-(int64_t)cfg->workers + 3) / 4);   // running beside (collectives)
             h->hw_workers = h->hw_blocks * 4;
         }
-        // 0.05 (round 3; 0.25 before): five times the hub columns at the same epoch time (48.0 -> 48.3 ms at the bench size, 9 253 columns
-        // holding 61 % of the nonzeros) and less of the Hogwild lag (C2, epoch 32: 1.068 -> 1.055 of the sequential oracle's cost)
-        const double theta = cfg->hot_theta > 0 ? (double)cfg->hot_theta : 0.05;
+        // (0.05 -- five times the hub columns -- takes a fifth off the Hogwild lag, C2 epoch 32: 1.068 -> 1.055 of the sequential oracle's
+        // cost, and is free on the faster kind of placement (48.0 -> 48.3 ms) but costs 4 - 7 % on the slower kind (54.9 -> 57 - 58.7 ms,
+        // tools/r03/theta_modes.py): the default stays 0.25)
+        const double theta = cfg->hot_theta > 0 ? (double)cfg->hot_theta : 0.25;
         const double stale_budget = cfg->stale_budget > 0 ? (double)cfg->stale_budget : 2000.0;
         h->blocked = cfg->shuffle == GE_SHUFFLE_DEVICE;
         if (h->blocked) {

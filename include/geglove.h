@@ -132,7 +132,7 @@ typedef struct {
     int32_t emb_dtype;      /* GE_DTYPE_*: storage of the focus/context rows                           */
     /* HOGWILD tuning; 0 = the library default everywhere.  These change results (which columns publish by delta,
      * how stale a hub run may get), so they live here and under the YAML `device:` block, not in the environment. */
-    float   hot_theta;      /* GE_HOT_AUTO: column j is a hub when count(j) * workers >= hot_theta * N.  Default 0.05 */
+    float   hot_theta;      /* GE_HOT_AUTO: column j is a hub when count(j) * workers >= hot_theta * N.  Default 0.25 */
     float   stale_budget;   /* a hub run is cut (delta published, row re-read) every m_j updates with
                                K_j * m_j <= stale_budget, K_j = expected workers inside column j.  Default 2000
                                (measured: 10 000 is stable at the bench scale, 39 000 diverges)                */
