@@ -98,6 +98,25 @@ __device__ __forceinline__ void wave_sync_lds() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
 }
+// minimum of an unsigned value over the wavefront: four DPP steps inside each row of 16 lanes, then the four rows through SGPRs
+// (a 64-bit butterfly of ds_bpermute pairs costs six LDS-crossbar round trips -- a quarter of a pop)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    auto step = [](uint32_t x, int ctrl) -> uint32_t {
+        uint32_t o;
+        switch (ctrl) {
+            case 0:  o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
+            case 1:  o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+            case 2:  o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x141, 0xF, 0xF, false); break;   // row_half_mirror
+            default: o = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)x, 0x140, 0xF, 0xF, false); break;   // row_mirror
+        }
+        return o < x ? o : x;
+    };
+    v = step(v, 0); v = step(v, 1); v = step(v, 2); v = step(v, 3);
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+    return a < b ? a : b;
+}
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     const unsigned lane = threadIdx.x & 63;
     return lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -273,7 +292,8 @@ __device__ bool bca_pass(const BcaParams &p, const BcaWork &w, int32_t bookmark,
 // DBLP-like graph) is left to the global-memory kernel: status 4.
 constexpr int LDS_HC = 768, LDS_MAX = 512, LDS_AC = 384;       // slots (load <= 2/3), nodes per bookmark, nodes at once in the TreeMap
 struct BcaHot {
-    int32_t *hkey; double *paint; float *val; int16_t *seq; int32_t *alist; int32_t *touched /* global: written here, read by the hand-over */;
+    int32_t *hkey; double *paint; float *val; int16_t *seq; int32_t *alist; int16_t *aslot /* the table slot of alist[i] */;
+    int32_t *touched /* global: written here, read by the hand-over */;
 };
 __device__ __forceinline__ uint32_t lds_home(int32_t key) { return (uint32_t)(((unsigned long long)((uint32_t)key * 2654435761u) * (unsigned long long)LDS_HC) >> 32); }
 __device__ __forceinline__ int32_t lds_find(const BcaHot &t, int32_t key) {
@@ -291,14 +311,10 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
         int32_t slot = 0; bool inserted = false;
         if (act) {
             uint32_t s = lds_home(nb);
-            for (int probe = 0;; ++probe) {
-                const int32_t k = __hip_atomic_load(t.hkey + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                if (k == nb) break;
-                if (k == KEY_EMPTY) {
-                    int32_t expected = KEY_EMPTY;
-                    if (__hip_atomic_compare_exchange_strong(t.hkey + s, &expected, nb, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)) { inserted = true; break; }
-                    if (expected == nb) break;
-                }
+            for (int probe = 0;; ++probe) {                  // one LDS atomic per probe: claim the slot if it is empty, else learn who holds it
+                int32_t expected = KEY_EMPTY;
+                if (__hip_atomic_compare_exchange_strong(t.hkey + s, &expected, nb, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)) { inserted = true; break; }
+                if (expected == nb) break;
                 s = s + 1 == (uint32_t)LDS_HC ? 0u : s + 1;
                 if (probe > LDS_HC) break;
             }
@@ -321,7 +337,7 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
         const unsigned long long mf = __ballot(fresh);
         if (fresh) {
             const int pos = an + __popcll(mf & lanemask_lt());
-            if (pos < LDS_AC) t.alist[pos] = nb;
+            if (pos < LDS_AC) { t.alist[pos] = nb; t.aslot[pos] = (int16_t)slot; }
         }
         an += __popcll(mf);
         if (an > LDS_AC) { if (lane == 0) *status = 4; return false; }
@@ -331,15 +347,14 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
 
     if (!tree_add(lane == 0, bookmark, 1.0)) return false;
     while (an > 0) {
-        unsigned long long best = ~0ull;
-        for (int i = lane; i < an; i += 64) {
-            const unsigned long long c = ((unsigned long long)(uint32_t)t.alist[i] << 32) | (uint32_t)i;
-            best = c < best ? c : best;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { const unsigned long long o = __shfl_xor(best, m, 64); best = o < best ? o : best; }
-        const int32_t focus = rfl((int)(best >> 32));
-        const int32_t fpos = rfl((int)(best & 0xFFFFFFFFull));
+        // pollFirstEntry(): the lowest node id of the active list (ids are unique in it, so exactly one lane holds the minimum)
+        uint32_t bid = 0xFFFFFFFFu; int32_t bpos = 0;
+        for (int i = lane; i < an; i += 64) { const uint32_t id = (uint32_t)t.alist[i]; if (id < bid) { bid = id; bpos = i; } }
+        const uint32_t mid = wave_min_u32(bid);
+        const int src = __ffsll((long long)__ballot(bid == mid)) - 1;
+        const int32_t focus = (int32_t)mid;
+        const int32_t fpos = __builtin_amdgcn_readlane(bpos, src);
+        const int32_t fslot = t.aslot[fpos];                 // the node's table slot rides beside its id: no probe for the pop
         // the graph reads of this pop do not depend on the table: issued first, they are under way while the table is worked on.
         // (One 64-byte line per vertex holding degree, total and the first six neighbours -- one access instead of two dependent ones
         // -- was tried: bit-identical, and 6 % SLOWER, 97.8 against 92.0 ms; the second read is not what a pop waits for.)
@@ -348,9 +363,8 @@ __device__ bool bca_pass_lds(const BcaParams &p, const BcaHot &t, int32_t bookma
         if (mode == 0) { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; total = p.g.tot_out[focus]; }
         else if (mode == 1) { ob = p.g.in_ptr[focus]; oe = p.g.in_ptr[focus + 1]; total = p.g.tot_in[focus]; }
         else { ob = p.g.out_ptr[focus]; oe = p.g.out_ptr[focus + 1]; ib = p.g.in_ptr[focus]; ie = p.g.in_ptr[focus + 1]; total = p.g.tot_und[focus]; }
-        if (lane == 0) t.alist[fpos] = t.alist[an - 1];
+        if (lane == 0) { t.alist[fpos] = t.alist[an - 1]; t.aslot[fpos] = t.aslot[an - 1]; }
         --an;
-        const int32_t fslot = lds_find(t, focus);
         const double wet = t.paint[fslot];
         const int32_t old_seq = t.seq[fslot];
         wave_sync_lds();
@@ -440,20 +454,21 @@ __global__ __launch_bounds__(64) void k_bca(BcaParams p) {
     const int wave = blockIdx.x;
     BcaWork w = carve(p, wave);
     // LDS, two views of one buffer: during the passes the hot table of the bookmark (paint 6 144 B | keys 3 072 | BCV values 3 072 |
-    // sequences 1 536 | active list 1 536); during the emission -- the passes' result has been handed to the global workspace by then --
+    // sequences 1 536 | active list 1 536 + its slots 768); during the emission -- the passes' result has been handed to the global workspace by then --
     // the sort keys of the row (4 096 B), the bin histogram / bin heads of the exact replay (4 096) and the row itself in iteration
     // order (values 2 048, keys 2 048), so that ranking, the treeify check and the sequential folds of the normalisation run on LDS.
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS ? 15360 : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS ? 16128 : 16];
     double *const s_paint = reinterpret_cast<double *>(s_raw);
     int32_t *const s_hkey = reinterpret_cast<int32_t *>(s_raw + (LDS ? 6144 : 0));
     float *const s_val = reinterpret_cast<float *>(s_raw + (LDS ? 9216 : 0));
     int16_t *const s_seq = reinterpret_cast<int16_t *>(s_raw + (LDS ? 12288 : 0));
     int32_t *const s_alist = reinterpret_cast<int32_t *>(s_raw + (LDS ? 13824 : 0));
+    int16_t *const s_aslot = reinterpret_cast<int16_t *>(s_raw + (LDS ? 15360 : 0));
     float *const e_x = reinterpret_cast<float *>(s_raw + (LDS ? 8192 : 0));
     int32_t *const e_j = reinterpret_cast<int32_t *>(s_raw + (LDS ? 10240 : 0));
     static_assert(LDS_HC == 768 && LDS_AC == 384 && LDS_MAX == 512, "the two LDS views are laid out for these sizes");
     if constexpr (LDS) { w.okey = reinterpret_cast<unsigned long long *>(s_raw); w.jhead = reinterpret_cast<int32_t *>(s_raw + 4096); }
-    const BcaHot hot{s_hkey, s_paint, s_val, s_seq, s_alist, w.touched};
+    const BcaHot hot{s_hkey, s_paint, s_val, s_seq, s_alist, s_aslot, w.touched};
     // table starts empty
     if constexpr (LDS) { for (int i = lane; i < LDS_HC; i += 64) s_hkey[i] = KEY_EMPTY; }
     else { for (int i = lane; i < p.hc; i += 64) w.hkey[i] = KEY_EMPTY; }
