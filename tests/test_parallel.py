@@ -288,3 +288,60 @@ def test_bench_launches_its_own_ranks_and_prints_no_line_without_gpus():
     assert r.returncode != 0
     assert "n_gpus" not in r.stdout
     assert "has no GPU" in r.stderr and "stopping the other ranks" in r.stderr
+
+
+# ---- the hub rows' small exchange (ge_sync_epoch), through the model --------------------------------------------------------
+
+def _hub_rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    V, D = 40, 6
+    rng = np.random.default_rng(5)                       # the same start on every rank
+    st = {"context": torch.from_numpy(rng.standard_normal((V, D)).astype(np.float32)), "cbias": torch.from_numpy(rng.standard_normal(V).astype(np.float32)),
+          "gsq_context": torch.from_numpy(1 + rng.random((V, D)).astype(np.float32)), "gsq_cbias": torch.from_numpy(1 + rng.random(V).astype(np.float32))}
+    start = {k: v.clone() for k, v in st.items()}
+    sync = SyncModel(sums=[st["context"].view(-1)], means=[st["cbias"]], lazy_sums=[st["gsq_context"].view(-1), st["gsq_cbias"]], lazy_every=1, wire="f32")
+    hubs = np.array([3, 17, 18], np.int64)
+    mine = np.random.default_rng(100 + rank)
+    moves = {k: (mine.standard_normal(v.shape) * 0.1 * (mine.random(v.shape) < 0.6)).astype(np.float32) for k, v in st.items()}
+    if rank == 1:
+        moves["cbias"][17] = 0.0                          # hub row 17's bias: moved by rank 0 only -> the mean is rank 0's move
+    for k in st:
+        st[k].add_(torch.from_numpy(moves[k]))
+    sync.hub_exchange(hubs, V)
+    after_hub = {k: v.clone() for k, v in st.items()}
+    sync.sync()                                           # the large exchange: nothing left to do for the hub rows
+    q.put((rank, {k: v.numpy() for k, v in start.items()}, moves, {k: v.numpy() for k, v in after_hub.items()}, {k: v.numpy().copy() for k, v in st.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_hub_rows_are_reconciled_exactly_and_left_alone_by_the_large_exchange():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hub_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = {}
+    for _ in range(world):
+        r, start, moves, after_hub, final = q.get(timeout=300)
+        got[r] = (start, moves, after_hub, final)
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    hubs = [3, 17, 18]
+    start = got[0][0]
+    for k in CTX:
+        a0, a1 = got[0][2][k].reshape(40, -1), got[1][2][k].reshape(40, -1)
+        np.testing.assert_array_equal(a0[hubs], a1[hubs])                       # after the small exchange the hub rows are identical ...
+        d0 = (start[k] + got[0][1][k]).astype(np.float32) - start[k]; d1 = (start[k] + got[1][1][k]).astype(np.float32) - start[k]
+        tot = (d0 + d1).reshape(40, -1)
+        if k == "cbias":
+            tot = tot / np.maximum((d0 != 0).astype(np.float32) + (d1 != 0), 1).reshape(40, -1)
+        np.testing.assert_array_equal(a0[hubs], (start[k].reshape(40, -1) + tot)[hubs])          # ... and are start + the merged moves
+        rest = np.setdiff1d(np.arange(40), hubs)
+        np.testing.assert_array_equal(a0[rest], (start[k] + got[0][1][k]).astype(np.float32).reshape(40, -1)[rest])   # nothing else moved
+        f0, f1 = got[0][3][k].reshape(40, -1), got[1][3][k].reshape(40, -1)
+        np.testing.assert_array_equal(f0, f1)                                    # after the large exchange (fp32 wire): replicas identical,
+        np.testing.assert_array_equal(f0[hubs], a0[hubs])                        # the hub rows untouched by it
+    assert got[0][2]["cbias"][17] == np.float32(start["cbias"][17] + got[0][1]["cbias"][17])      # the mean over ONE mover
