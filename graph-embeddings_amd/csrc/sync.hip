@@ -350,7 +350,6 @@ struct ge_sync {
     uint32_t seed = 0x5EED;
     int32_t *hub_list = nullptr; int32_t n_hub = 0;       // the union of the ranks' hub columns (ascending), on the device
     float *hub_buf = nullptr;                              // [n_hub x (2 D + 3)] fp32: the hub rows' deltas of one small exchange
-    void *hub_ticket = nullptr;
     ge_context_layout lay{};
     template <typename T> hipError_t alloc(T **out, size_t n) {
         hipError_t e = hipMalloc((void **)out, sizeof(T) * std::max<size_t>(n, 1));
