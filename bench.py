@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--exchange", default="overlap", choices=["overlap", "sync"],
                     help="N>1: 'overlap' runs the all-reduce of step k's context deltas under step k+1 (they land one step late); "
                          "'sync' exchanges after every step before the next one starts")
+    ap.add_argument("--sync-first", type=int, default=2, help="N>1 with --exchange overlap: this many first steps are exchanged synchronously (at most --warmup of them)")
     ap.add_argument("--reserve-waves", type=int, default=256,
                     help="N>1 with --exchange overlap: wavefront slots the epoch kernel leaves free for the all-reduce kernels")
     ap.add_argument("--workers", type=int, default=0, help="sequential workers (wavefronts); 0 = fill the device (cfg.workers)")
@@ -226,7 +227,9 @@ def main():
         # N > 1: ge_sync_epoch -- the rank's epoch in segments, the hub rows of the context side reconciled behind each
         c = sync.epoch(it, args.hub_segments) if (sync is not None and args.hub_segments >= 0) else opt.epoch(it)
         if sync is not None and (it + 1) % args.sync_every == 0:
-            if (form or args.exchange) == "overlap":
+            # the first epochs of a run move the model most: they are exchanged synchronously (no epoch-2 bump from landing everything one
+            # step late), the overlapped form takes over after them -- never inside the timed region (capped by --warmup)
+            if (form or args.exchange) == "overlap" and it >= min(args.sync_first, args.warmup):
                 sync.turn()                         # lands the deltas sent one exchange ago and sends this step's: the all-reduce runs under the next epoch
             else:
                 sync.sync()

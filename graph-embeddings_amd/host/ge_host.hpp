@@ -1023,7 +1023,9 @@ public:
             for (int iteration = 0; iteration < config_.opt.maxiter; ++iteration) {
                 double c = 0;
                 check(ge_sync_epoch(sy, iteration, config_.device.hub_segments, &c));     // the epoch, hub rows reconciled on the way
-                check(overlap ? ge_sync_turn(sy) : ge_sync_sync(sy));
+                // the first two epochs move the model most: exchanged synchronously even in the overlapped form (no bump from landing
+                // everything one step late while the busiest rows still grow), the overlap takes over from the third
+                check(overlap && iteration >= 2 ? ge_sync_turn(sy) : ge_sync_sync(sy));
                 cost[(size_t)r] = c;
                 bar.wait();
                 if (r == 0) {                                   // Optimizer.optimize's tolerance logic, once for all ranks

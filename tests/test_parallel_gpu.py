@@ -345,7 +345,7 @@ def _run_rank_threads(world, V, N, D, epochs, exchange, wire, dtype="f32", lazy_
                 if fail_rank == r and it == 1:
                     raise RuntimeError("rank %d leaves" % r)
                 cost[it, r] = sync.epoch(it) if hub_segments is None else (sync.epoch(it, hub_segments) if hub_segments > 0 else opt.epoch(it))
-                sync.turn() if exchange == "overlap" else sync.sync()
+                sync.turn() if (exchange == "overlap" and it >= 2) else sync.sync()      # (the hosts' policy: two synchronous epochs first)
             sync.replicate()
             out[r] = {k: opt.get_state(k) for k in CTX}
         except Exception as e:              # noqa: BLE001 -- reported by the caller
