@@ -77,11 +77,13 @@ else:
                                  "device": dict({"mode": "hogwild", "shuffle": "device", "seed": 42},
                                                 **{k: (float(v) if "." in v else int(v)) for k, v in (kv.split("=") for kv in a.device_cfg.split(",") if kv)})})
     opt = geglove.Adagrad(geglove.CooMatrix(a.V, I, J, X, xmax), cfg, cfg.costFunction())
-    dev = [opt.epoch(it) / n for it in range(epochs)]
+    dev, kms = [], []
+    for it in range(epochs):
+        dev.append(opt.epoch(it) / n); kms.append(opt.last_kernel_ms()[0])
     E = opt.extractResult().reshape(a.V, a.D)[sample]
     rc = ref["costs"][:epochs]
     rho = float(np.corrcoef(cos_upper(E), cos_upper(ref["vectors"].astype(np.float64)))[0, 1])
-    out = {"device_cfg": a.device_cfg, "workload": "BASELINE C2: V=%d, %d nonzeros, dim %d, glove, AdaGrad, seed 42" % (a.V, n, a.D), "epochs": epochs,
+    out = {"device_cfg": a.device_cfg, "kernel_ms_median": float(np.median(kms)), "workload": "BASELINE C2: V=%d, %d nonzeros, dim %d, glove, AdaGrad, seed 42" % (a.V, n, a.D), "epochs": epochs,
            "workers": opt.info()["groups_in_flight"],
            "device_cost": dev, "oracle_cost": rc.tolist(), "device_over_oracle": (np.array(dev) / rc).tolist(),
            "oracle_threads": int(ref["threads"]),
