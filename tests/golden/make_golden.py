@@ -51,5 +51,5 @@ if __name__ == "__main__":
 
 
 # c2_oracle_costs.npz: the first 16 per-epoch mean costs of the sequential oracle on BASELINE C2 (V = 100 k, 10.0 M nonzeros, dim 100,
-# glove, Java order, seed 42), cut from profiles/r03_convergence_oracle.npz, which `python3 tools/r03/convergence.py oracle --epochs 48
+# glove, Java order, seed 42), cut from profiles/r03_convergence_oracle.npz, which `python3 tests/tools/convergence_oracle.py --epochs 48
 # --out profiles/r03_convergence_oracle.npz` writes (restatement-generated, not Java-generated; 20 s per epoch on one core).

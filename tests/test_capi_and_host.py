@@ -212,10 +212,12 @@ def test_measurement_scripts_compile():
     import glob
     import py_compile
     scripts = (glob.glob(os.path.join(REPO, "tools", "*.py")) + glob.glob(os.path.join(REPO, "tools", "r02", "*.py")) +
-               glob.glob(os.path.join(REPO, "tests", "tools", "*.py")))
+               glob.glob(os.path.join(REPO, "tools", "r03", "*.py")) + glob.glob(os.path.join(REPO, "tests", "tools", "*.py")))
     assert len(scripts) >= 10
     for path in scripts:
         py_compile.compile(path, doraise=True)
     # the scripts that load the CPU oracle live under tests/ (oracle/ is test infrastructure)
-    for path in glob.glob(os.path.join(REPO, "tools", "*.py")) + glob.glob(os.path.join(REPO, "tools", "r02", "*.py")):
-        assert "import oracle" not in open(path).read(), path
+    for path in (glob.glob(os.path.join(REPO, "tools", "*.py")) + glob.glob(os.path.join(REPO, "tools", "r02", "*.py")) +
+                 glob.glob(os.path.join(REPO, "tools", "r03", "*.py"))):
+        text = open(path).read()
+        assert "import oracle" not in text and "from helpers import" not in text, path          # (tests/helpers.py loads the oracle)

@@ -35,7 +35,7 @@ def test_c2_full_size_cost_trajectory(gpu):
     EP = 10
     dev = np.array([opt.epoch(it) / n for it in range(EP)])
     # the sequential oracle's trajectory on this matrix and seed is a committed fixture (tests/golden/c2_oracle_costs.npz, written by
-    # tools/r03/convergence.py's oracle leg: 20 s per epoch on one core); its first two epochs are recomputed here to tie the file to the code
+    # tests/tools/convergence_oracle.py: 20 s per epoch on one core); its first two epochs are recomputed here to tie the file to the code
     gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c2_oracle_costs.npz"))
     assert int(gold["nnz"]) == n and int(gold["V"]) == V and int(gold["D"]) == D
     ora = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)

@@ -2,10 +2,10 @@
 """Long-run convergence of the production path against the sequential reference order (Optimizer.java:96-107).
 
 BASELINE C2 (V = 100 k, 10.0 M nonzeros, dim 100, glove, AdaGrad), 40+ epochs:
-  oracle leg  (CPU, no GPU needed; run once, result committed under profiles/):
-      python3 tools/r03/convergence.py oracle --epochs 48 --out profiles/r03_convergence_oracle.npz
-      the sequential restatement of Adagrad.createJob, Java order (Fisher-Yates per epoch, seed 42): per-epoch mean cost and the
-      final vectors of a fixed vertex sample.  tools/ never load oracle/ in the product path: this leg IS the checker.
+  oracle leg  (CPU, no GPU needed; run once, result committed under profiles/): tests/tools/convergence_oracle.py (the scripts that load
+      the CPU oracle live under tests/): python3 tests/tools/convergence_oracle.py --epochs 48 --out profiles/r03_convergence_oracle.npz
+      -- the sequential restatement of Adagrad.createJob, Java order (Fisher-Yates per epoch, seed 42): per-epoch mean cost and the
+      final vectors of a fixed vertex sample.
   device leg  (GPU): python3 tools/r03/convergence.py device --ref profiles/r03_convergence_oracle.npz --out profiles/r03_convergence.json
       the Hogwild kernel, blocked device shuffle, library-default workers, same matrix and seed: per-epoch cost ratio, the epoch at
       which |prev - cur| <= tolerance fires on each side for the shipped tolerance 1e-4 (and for 1e-5, 1e-6), pairwise-cosine
@@ -23,13 +23,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(REPO, "graph-embeddings_amd"))
 
 ap = argparse.ArgumentParser()
-ap.add_argument("leg", choices=["oracle", "device"])
+ap.add_argument("leg", choices=["device"])
 ap.add_argument("--V", type=int, default=100_000)
 ap.add_argument("--N", type=int, default=12_100_000)        # the generator drops duplicate (i, j): 10.0 M remain
 ap.add_argument("--D", type=int, default=100)
 ap.add_argument("--epochs", type=int, default=48)
 ap.add_argument("--sample", type=int, default=2000)
-ap.add_argument("--threads", type=int, default=1, help="oracle leg: 1 = sequential (the reference of the comparison)")
 ap.add_argument("--ref")
 ap.add_argument("--device-cfg", default="", help="device leg: extra keys of the YAML's device: block, k=v,k=v (hot_theta, stale_budget, workers ...)")
 ap.add_argument("--out", required=True)
@@ -56,18 +55,7 @@ def cos_upper(E):
     return (nrm @ nrm.T)[np.triu_indices(len(E), 1)]
 
 
-if a.leg == "oracle":
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import oracle as O
-    ora = O.Glove(a.V, a.D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=a.threads)
-    costs, t0 = [], time.time()
-    for it in range(a.epochs):
-        costs.append(float(ora.epoch(race=a.threads > 1)))
-        print("oracle epoch %d cost %.8f (%.0f s)" % (it + 1, costs[-1], time.time() - t0), flush=True)
-    E = ora.extract().reshape(a.V, a.D)[sample].astype(np.float32)
-    np.savez_compressed(a.out, costs=np.array(costs), sample=sample, vectors=E, nnz=n, V=a.V, D=a.D, threads=a.threads)
-    print("wrote", a.out)
-else:
+if True:
     import geglove
     ref = np.load(a.ref)
     assert int(ref["nnz"]) == n and int(ref["V"]) == a.V and int(ref["D"]) == a.D and np.array_equal(ref["sample"], sample)
