@@ -2,8 +2,6 @@
 set -o pipefail
 O=gpurun_out/r03/call3; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-echo "== replicate debug"; timeout -k 10 300 python3 tools/r03/replicate_debug.py 8 bf16 > $O/replicate_debug.txt 2>&1; grep -c "differing" $O/replicate_debug.txt; grep -v ": 0 of" $O/replicate_debug.txt | head -12
-timeout -k 10 300 python3 tools/r03/replicate_debug.py 8 f32 > $O/replicate_debug_f32.txt 2>&1; grep -v ": 0 of" $O/replicate_debug_f32.txt | head -6
 echo "== xcd locality"; ./tools/r03/micro/xcd_locality > $O/xcd_hipmalloc.csv 2> $O/xcd.err || tail -3 $O/xcd.err
 ./tools/r03/micro/xcd_locality contiguous > $O/xcd_contig.csv 2>> $O/xcd.err || tail -3 $O/xcd.err
 python3 - $O <<'PY'

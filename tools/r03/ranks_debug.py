@@ -4,7 +4,7 @@ eight-rank test.   python3 tools/r03/ranks_debug.py world exchange wire lazy_eve
 import os, sys, threading
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path[:0] = [os.path.join(REPO, "graph-embeddings_amd"), os.path.join(REPO, "tests")]
+sys.path.insert(0, os.path.join(REPO, "graph-embeddings_amd"))
 import geglove
 from geglove import parallel, synth
 
