@@ -1764,8 +1764,8 @@ ge_status glove_epoch_finish(ge_glove *h, double *cost_sum) {
     if (cost_sum) *cost_sum = total;
     return GE_OK;
 }
-// the hub columns of this handle's layout (ascending), for the exchange of a sharded run
-const std::vector<int32_t> *glove_hub_columns(const ge_glove *h) { return h ? &h->lay.hubs : nullptr; }
+// the busy columns of this handle's shard (ascending; ge_layout.h `heavy`), for the small exchanges of a sharded run
+const std::vector<int32_t> *glove_hub_columns(const ge_glove *h) { return h ? &h->lay.heavy : nullptr; }
 // what sync.hip needs to know about a handle (struct ge_glove is private to this file)
 ge_status glove_sync_view(ge_glove *h, int32_t *opt, int32_t *mode, void **stream, int32_t *device) {
     if (!h) return ge::fail(GE_ERR_ARG, "null ge_glove handle");

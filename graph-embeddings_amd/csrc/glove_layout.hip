@@ -164,6 +164,14 @@ ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const 
     for (int32_t c : hubs) out->flush_min = std::min(out->flush_min, flush_limit(c));
     if (rq.want_hub_index) { out->hub_index = hub_rank; out->n_hub = n_hub; }
     out->hubs = hubs;
+    // The columns a SHARDED run reconciles inside the epoch (ge_sync_epoch): busy enough that a rank pushes them hard within one epoch.
+    // Independent of this handle's worker count and of cfg.hot_columns (those are about concurrency INSIDE the GPU): count >= N / 20 480
+    // -- what the hub rule gives a full device, 0.25 N / 5 120 -- and at least 256.
+    out->heavy.clear();
+    {
+        const int64_t thr = std::max<int64_t>(256, N / 20480);
+        for (int32_t v = 0; v < V; ++v) if (cnt[(size_t)v] >= thr) out->heavy.push_back(v);
+    }
 
     // ---- stable sort: hubs column-major, the rest grouped by row ----
     int32_t *d_rank = nullptr; uint32_t *d_key = nullptr, *d_skey = nullptr; int32_t *d_val = nullptr, *d_sval = nullptr;

@@ -701,8 +701,9 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
                 if (rccl().CommSplit(s->comm, 0, cfg->rank, &c2, nullptr) == ncclSuccess && c2) s->hub_comm = c2;
             }
         }
-        // The hub rows of the small exchanges (ge_sync_epoch): the union of the ranks' hub columns (every rank flags its own in a
-        // [V] vector, the vector is summed).  A bf16 handle keeps the fp32 masters of ITS hubs, and a column that is a
+        // The hub rows of the small exchanges (ge_sync_epoch): the union of the ranks' busy columns -- count on the rank >= max(256,
+        // N_rank / 20 480), whatever the handle's worker count or hot-column setting (every rank flags its own in a [V] vector, the
+        // vector is summed).  A bf16 handle keeps the fp32 masters of ITS hubs, and a column that is a
         // hub on one rank and an ordinary bf16 row on another is written back as each rank stores it (k_hub_land).
         {
             const std::vector<int32_t> *mine = ge::glove_hub_columns(h);

@@ -444,7 +444,7 @@ ge_status ge_sync_turn(ge_sync *s);
 ge_status ge_sync_sync(ge_sync *s);
 /* One epoch of a sharded run, to be called INSTEAD of ge_glove_epoch by every rank (collective): the handle's epoch runs in
  * `segments` launches (<= 0: the number of ranks, at least 8; at most 64) and behind each one the HUB rows of the context side
- * -- the union of the ranks' hub columns, a few thousand rows -- are reconciled exactly in one small fp32 all-reduce (rows and both
+ * -- the union of the ranks' busy columns (count on a rank >= max(256, N_rank / 20 480)), a few thousand rows -- are reconciled exactly in one small fp32 all-reduce (rows and both
  * accumulators summed, cBias averaged over the ranks that moved it).  Without it eight ranks that each push a busy row for a whole
  * epoch from the same start overshoot where one GPU settles (measured: DESIGN.md 7); inside a GPU the same rows are held together by
  * publishing deltas every few updates, across GPUs by this.  ge_sync_turn / ge_sync_sync follow as before (they find nothing left to

@@ -122,8 +122,8 @@ def _model_rank_main(rank, world, port, q, D, layout, steps, with_hubs=False):
     from sync_model import SyncModel
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    V = 300
-    I, J, X, xmax = synth.synthetic_coo(V, 3000, seed=3)
+    V = 2000 if with_hubs else 300                                  # (busy columns: at least 256 nonzeros on a rank, so 1 000 rows per rank)
+    I, J, X, xmax = synth.synthetic_coo(V, 150000 if with_hubs else 3000, seed=3)
     rows = parallel.shard_rows(V, world, rank)
     si, sj, sx = parallel.shard_nonzeros(I, J, X, rows)
     cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, row_range=rows, layout=layout)
