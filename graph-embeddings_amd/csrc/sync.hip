@@ -600,10 +600,16 @@ ge_status ge_rccl_selftest(int32_t device) {
     ncclResult_t nr = ncclSuccess;
     if (he == hipSuccess) nr = rccl().AllReduce(d, d, (size_t)n, ncclFloat32, ncclSum, comm, side);
     if (he == hipSuccess && nr == ncclSuccess) nr = rccl().Broadcast(d, d, (size_t)n, ncclFloat32, 0, comm, side);
+    ncclComm_t comm2 = nullptr;                      // the second communicator ge_sync makes for the hub rows (ncclCommSplit), used the same way
+    if (he == hipSuccess && nr == ncclSuccess && rccl().CommSplit) {
+        nr = rccl().CommSplit(comm, 0, 0, &comm2, nullptr);
+        if (nr == ncclSuccess && comm2) nr = rccl().AllReduce(d, d, (size_t)n, ncclFloat32, ncclSum, comm2, side);
+    }
     if (he == hipSuccess && nr == ncclSuccess) he = hipMemcpyAsync(back.data(), d, sizeof(float) * n, hipMemcpyDeviceToHost, side);
     if (he == hipSuccess && nr == ncclSuccess) he = hipStreamSynchronize(side);
     if (d) (void)hipFree(d);
     if (side) (void)hipStreamDestroy(side);
+    if (comm2) (void)rccl().CommDestroy(comm2);
     (void)rccl().CommDestroy(comm);
     if (nr != ncclSuccess) return ge::fail(GE_ERR_HIP, "RCCL self-test: %s", rccl().GetErrorString(nr));
     if (he != hipSuccess) return ge::fail(GE_ERR_HIP, "RCCL self-test: %s", hipGetErrorString(he));
@@ -695,10 +701,16 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
             GE_TRYS(hipStreamCreateWithFlags(&s->hub_side, hipStreamNonBlocking));
             GE_TRYS(hipEventCreateWithFlags(&s->ev_hub_a, hipEventDisableTiming));
             GE_TRYS(hipEventCreateWithFlags(&s->ev_hub_b, hipEventDisableTiming));
+            // The hub rows' communicator: a split of the first one (every rank makes the same choice: the symbol is there or it is not,
+            // GE_SYNC_HUB_COMM=shared turns it off everywhere; a split that fails is an error, not a silent fallback that would leave
+            // the ranks on different communicators)
             s->hub_comm = s->comm;
-            if (rccl().CommSplit) {
+            const char *hc = std::getenv("GE_SYNC_HUB_COMM");
+            if (rccl().CommSplit && !(hc && std::strcmp(hc, "shared") == 0)) {
                 ncclComm_t c2 = nullptr;
-                if (rccl().CommSplit(s->comm, 0, cfg->rank, &c2, nullptr) == ncclSuccess && c2) s->hub_comm = c2;
+                ncclResult_t r2 = rccl().CommSplit(s->comm, 0, cfg->rank, &c2, nullptr);
+                if (r2 != ncclSuccess || !c2) { ge_status e2 = ge::fail(GE_ERR_HIP, "ncclCommSplit failed: %s (GE_SYNC_HUB_COMM=shared uses one communicator)", rccl().GetErrorString(r2)); ge_sync_destroy(s); return e2; }
+                s->hub_comm = c2;
             }
         }
         // The hub rows of the small exchanges (ge_sync_epoch): the union of the ranks' busy columns -- count on the rank >= max(256,
