@@ -35,6 +35,7 @@
 #include <new>
 #include <thread>
 #include <vector>
+#include <sys/mman.h>
 
 namespace {
 
@@ -844,8 +845,31 @@ struct PhaseClock {
 struct ge_coo {
     int64_t nnz = 0;
     int32_t V = 0;
-    std::unique_ptr<int32_t[]> I, J;      // nnz entries each; left uninitialised until the device copy fills them
-    std::unique_ptr<float[]> X;           //   (a value-initialising container would touch 12 bytes per entry once more)
+    struct Free { void operator()(void *q) const { std::free(q); } };
+    std::unique_ptr<int32_t[], Free> I, J;      // nnz entries each; left uninitialised until the device copy fills them
+    std::unique_ptr<float[], Free> X;           //   (a value-initialising container would touch 12 bytes per entry once more)
+    int64_t capacity = 0;                       // entries each array has room for (>= nnz)
+    // Fresh host memory costs more than the copy into it: 520 MB of J and X arrive in 9 ms once their pages exist and in 35 - 60 ms when
+    // every page is met for the first time (tools/r03/pinned_probe.py).  The arrays are therefore allocated BEFORE the main launch, from
+    // the sample's estimate of the total, and their pages are touched by host threads while the device works.
+    bool reserve(int64_t entries) {
+        const size_t bytes = ((size_t)std::max<int64_t>(entries, 1) * 4 + 4095) / 4096 * 4096;
+        void *q[3] = {nullptr, nullptr, nullptr};
+        for (int k = 0; k < 3; ++k)
+            if (posix_memalign(&q[k], (size_t)1 << 21, bytes) != 0) { for (int j = 0; j < k; ++j) std::free(q[j]); return false; }
+        for (int k = 0; k < 3; ++k) (void)madvise(q[k], bytes, MADV_HUGEPAGE);      // where the system allows it: 2 MB pages, 512 times fewer faults
+        I.reset(static_cast<int32_t *>(q[0])); J.reset(static_cast<int32_t *>(q[1])); X.reset(static_cast<float *>(q[2]));
+        capacity = (int64_t)(bytes / 4);
+        return true;
+    }
+    // one write per 4 KB page of the first `entries` entries of the three arrays, slice t of n
+    void touch(int64_t entries, int t, int n) {
+        const int64_t pages = (std::min(entries, capacity) * 4 + 4095) / 4096;
+        for (int a = 0; a < 3; ++a) {
+            volatile char *base = a == 0 ? reinterpret_cast<char *>(I.get()) : a == 1 ? reinterpret_cast<char *>(J.get()) : reinterpret_cast<char *>(X.get());
+            for (int64_t pg = pages * t / n, p1 = pages * (t + 1) / n; pg < p1; ++pg) base[pg * 4096] = 0;
+        }
+    }
     std::vector<int64_t> row_ptr;
     double max = 0;
 };
@@ -999,6 +1023,13 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     Guard work_guard{[&] { free_work(wmain); free_work(wglob); }};
     auto grow = [&](int32_t status) { if (status == 1) hc *= 4; else ac = std::min<int64_t>(ac * 4, (int64_t)V + 64); };
 
+    // the result object exists from here on: its host arrays are sized from the sample and their pages touched while the main launch runs
+    std::unique_ptr<ge_coo> cown(new (std::nothrow) ge_coo());
+    if (!cown) return ge::fail(GE_ERR_OOM, "host allocation failed");
+    std::vector<std::thread> prefault;
+    Guard prefault_guard{[&] { for (auto &th : prefault) if (th.joinable()) th.join(); }};      // (declared after cown: joins before the arrays go)
+    int64_t est_total = 0;
+
     int32_t status = 0; unsigned long long used = 0;
     for (int attempt = 0;; ++attempt) {
         if (attempt > 12) return ge::fail(GE_ERR_OVERFLOW, "BCA work buffers kept overflowing (table %lld, active list %lld, pool %lld)", (long long)hc, (long long)ac, (long long)pool_cap);
@@ -1017,6 +1048,7 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
             if (!use_lds && (status == 1 || status == 2)) { grow(status); continue; }
             const double mean = (double)used / (double)n_sample;            // pool_used counted every sampled row that ran through
             pool_cap = std::max<int64_t>(1 << 16, (int64_t)(mean * 1.25 * (double)n_rows) + 65536);
+            est_total = (int64_t)(mean * (double)n_rows);
             sampled = true;
         }
         if (d_pJ) { (void)hipFree(d_pJ); d_pJ = nullptr; }
@@ -1026,6 +1058,13 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
             if (d_pJ) (void)hipFree(d_pJ);
             if (d_pX) (void)hipFree(d_pX);
             return ge::fail(GE_ERR_OOM, "device allocation failed for the BCA pool (%lld entries)", (long long)pool_cap);
+        }
+        if (est_total >= ((int64_t)1 << 22) && prefault.empty() && cown->capacity == 0 && !std::getenv("GE_BCA_NO_PREFAULT")
+            && cown->reserve(est_total + est_total / 8 + 65536)) {
+            const int n_touch = (int)std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+            ge_coo *const cc = cown.get();
+            const int64_t upto = est_total + est_total / 50;
+            for (int t = 0; t < n_touch; ++t) prefault.emplace_back([cc, upto, t, n_touch] { cc->touch(upto, t, n_touch); });
         }
         if ((st = run(wmain, nullptr, n_rows, d_pJ, d_pX, pool_cap, 0, &status, &used)) != GE_OK) { (void)hipFree(d_pJ); (void)hipFree(d_pX); return st; }
         if (!use_lds && (status == 1 || status == 2)) { grow(status); continue; }
@@ -1076,8 +1115,9 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     }
     clk.lap("upload + k_bca passes");
 
-    ge_coo *c = new (std::nothrow) ge_coo();
-    if (!c) return ge::fail(GE_ERR_OOM, "host allocation failed");
+    for (auto &th : prefault) th.join();
+    prefault.clear();
+    ge_coo *c = cown.release();
     c->V = V;
     std::vector<float> h_max((size_t)n_rows);
     hipError_t e = hipMemcpy(h_n.data(), d_row_n, sizeof(int32_t) * (size_t)n_rows, hipMemcpyDeviceToHost);
@@ -1097,7 +1137,7 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
     for (int32_t r = 0; r < n_rows; ++r) mx = java_math_max(mx, (double)h_max[(size_t)r]);
     c->max = mx;
     clk.lap("row sizes, offsets, max");
-    c->I.reset(new int32_t[(size_t)std::max<int64_t>(total, 1)]); c->J.reset(new int32_t[(size_t)std::max<int64_t>(total, 1)]); c->X.reset(new float[(size_t)std::max<int64_t>(total, 1)]);
+    if (c->capacity < std::max<int64_t>(total, 1) && !c->reserve(total)) { delete c; return ge::fail(GE_ERR_OOM, "host allocation failed for the COO (%lld entries)", (long long)total); }
     clk.lap("host result arrays");
     if (total > 0) {
         int64_t *d_dst = nullptr; int32_t *d_I = nullptr, *d_J = nullptr; float *d_X = nullptr;
@@ -1123,8 +1163,33 @@ static ge_status ge_bca_build_impl(const ge_csr *out_nbrs, const ge_csr *in_nbrs
                 for (int32_t r = (int32_t)((int64_t)n_rows * t / n_fill), r1 = (int32_t)((int64_t)n_rows * (t + 1) / n_fill); r < r1; ++r)
                     std::fill(hI + dst[(size_t)r], hI + dst[(size_t)r] + h_n[(size_t)r], rb + r);
             });
-        if (e == hipSuccess) e = hipMemcpy(c->J.get(), d_J, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(c->X.get(), d_X, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost);
+        // J and X into fresh pageable memory: a copy of that kind is staged through the runtime's pinned buffers by the calling thread
+        // (and meets every page of the destination for the first time), so it is one host thread's work -- slices on several threads
+        // run side by side (GE_BCA_COPY_THREADS, default 4; 1 = the two plain copies)
+        int n_copy = 4;
+        if (const char *ev = std::getenv("GE_BCA_COPY_THREADS")) n_copy = std::max(1, std::min(16, std::atoi(ev)));
+        if (total < ((int64_t)1 << 22)) n_copy = 1;
+        if (e == hipSuccess && n_copy == 1) {
+            e = hipMemcpy(c->J.get(), d_J, sizeof(int32_t) * (size_t)total, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(c->X.get(), d_X, sizeof(float) * (size_t)total, hipMemcpyDeviceToHost);
+        } else if (e == hipSuccess) {
+            std::vector<hipError_t> err((size_t)n_copy, hipSuccess);
+            std::vector<std::thread> copy;
+            const int device = cfg->device;
+            char *const hJ = reinterpret_cast<char *>(c->J.get()), *const hX = reinterpret_cast<char *>(c->X.get());
+            const char *const dJb = reinterpret_cast<const char *>(d_J), *const dXb = reinterpret_cast<const char *>(d_X);
+            for (int t = 0; t < n_copy; ++t)
+                copy.emplace_back([&, t] {
+                    hipError_t q = hipSetDevice(device);
+                    // slice t of the 2 * total words [J | X]
+                    const int64_t w0 = 2 * total * t / n_copy, w1 = 2 * total * (t + 1) / n_copy;
+                    if (q == hipSuccess && w0 < total) q = hipMemcpy(hJ + 4 * w0, dJb + 4 * w0, (size_t)(4 * (std::min(w1, total) - w0)), hipMemcpyDeviceToHost);
+                    if (q == hipSuccess && w1 > total) { const int64_t x0 = std::max(w0, total) - total; q = hipMemcpy(hX + 4 * x0, dXb + 4 * x0, (size_t)(4 * (w1 - total - x0)), hipMemcpyDeviceToHost); }
+                    err[(size_t)t] = q;
+                });
+            for (auto &th : copy) th.join();
+            for (hipError_t q : err) if (q != hipSuccess) e = q;
+        }
         for (auto &th : fill) th.join();
         if (e != hipSuccess) { delete c; return ge::fail(GE_ERR_HIP, "COO gather failed: %s", hipGetErrorString(e)); }
         clk.lap("copy out");

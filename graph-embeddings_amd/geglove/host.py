@@ -142,6 +142,30 @@ def _csr_struct(V, csr, keep):
     return capi.Csr(V, _p(ptr, C.c_int64), _p(idx, C.c_int32), _p(w, C.c_float))
 
 
+class _CooOwner:
+    """Keeps a ge_coo alive for the numpy views of its arrays: every view's buffer object refers to this owner."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def view(self, ptr, ctype, count, dtype):
+        if count <= 0:
+            return np.empty(0, dtype)
+        buf = (ctype * count).from_address(C.addressof(ptr.contents))
+        buf._owner = self
+        a = np.frombuffer(buf, dtype=dtype, count=count)
+        a.flags.writeable = False
+        return a
+
+    def __del__(self):
+        try:
+            if self._h and self._h.value:
+                capi.lib().ge_coo_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
 class BookmarkColoring(CooMatrix):
     """`new BookmarkColoring(graph, config)` (J/bca/BookmarkColoring.java:32-120) on the device.
 
@@ -163,18 +187,16 @@ class BookmarkColoring(CooMatrix):
                           int(dev.get("bca_table_slots", 0)), int(dev.get("bca_pool_entries", 0)))
         h = C.c_void_p()
         capi.check(capi.lib().ge_bca_build(C.byref(out_s), C.byref(in_s), C.byref(cfg), C.byref(h)))
-        try:
-            nnz = C.c_int64(); mx = C.c_double()
-            pI = C.POINTER(C.c_int32)(); pJ = C.POINTER(C.c_int32)(); pX = C.POINTER(C.c_float)()
-            pR = C.POINTER(C.c_int64)()
-            capi.check(capi.lib().ge_coo_get(h, C.byref(nnz), C.byref(pI), C.byref(pJ), C.byref(pX), C.byref(pR), C.byref(mx)))
-            n = nnz.value
-            I = np.ctypeslib.as_array(pI, shape=(max(n, 1),))[:n].copy()
-            J = np.ctypeslib.as_array(pJ, shape=(max(n, 1),))[:n].copy()
-            X = np.ctypeslib.as_array(pX, shape=(max(n, 1),))[:n].copy()
-            self.row_ptr = np.ctypeslib.as_array(pR, shape=(V + 1,)).copy()
-        finally:
-            capi.lib().ge_coo_destroy(h)
+        owner = _CooOwner(h)                 # the arrays below are VIEWS of the library's result (780 MB at 65 M entries: no copies); it is
+        nnz = C.c_int64(); mx = C.c_double()  # destroyed when the last of them goes
+        pI = C.POINTER(C.c_int32)(); pJ = C.POINTER(C.c_int32)(); pX = C.POINTER(C.c_float)()
+        pR = C.POINTER(C.c_int64)()
+        capi.check(capi.lib().ge_coo_get(h, C.byref(nnz), C.byref(pI), C.byref(pJ), C.byref(pX), C.byref(pR), C.byref(mx)))
+        n = nnz.value
+        I = owner.view(pI, C.c_int32, n, np.int32)
+        J = owner.view(pJ, C.c_int32, n, np.int32)
+        X = owner.view(pX, C.c_float, n, np.float32)
+        self.row_ptr = owner.view(pR, C.c_int64, V + 1, np.int64).copy()
         super().__init__(V, I, J, X, mx.value, graph.get("keys"), graph.get("types"))
 
 
