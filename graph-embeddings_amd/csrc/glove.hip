@@ -64,7 +64,6 @@ struct GloveParams {
     float lr;
     int32_t order_mode;
     uint32_t bij_mask, bij_shift;
-    int64_t win_m;            // experiment (GE_ORDER_WINDOWS): > 0: the bijection permutes inside consecutive windows of win_m chunks
     uint32_t bij_key[4];
 };
 
@@ -503,16 +502,7 @@ __global__ __launch_bounds__(256, (NCH == 1 && VW == 4 && OPT == GE_OPT_ADAGRAD)
         int32_t c_lo = 0, c_len = 0, c_meta = -1;
         if (p.blocked) {
             uint32_t x = (uint32_t)tk;
-            if (p.order_mode == ORDER_BIJECTION) {
-                if (p.win_m > 0) {
-                    const int64_t w = tk / p.win_m;
-                    x = (uint32_t)(tk - w * p.win_m);
-                    do { x = bij_round(x, p); } while ((int64_t)x >= p.win_m);
-                    const int64_t c = w * p.win_m + x;
-                    if (c >= n_chunks) continue;                     // the last window's padding
-                    x = (uint32_t)c;
-                } else { do { x = bij_round(x, p); } while ((int64_t)x >= n_chunks); }
-            }
+            if (p.order_mode == ORDER_BIJECTION) { do { x = bij_round(x, p); } while ((int64_t)x >= n_chunks); }
             chunk = rfl((int)x);
             res_is_ctx = chunk < p.n_hchunks;
             c_lo = rfl(p.cstart[chunk]); c_len = rfl(p.cstart[chunk + 1]) - c_lo; c_meta = rfl(p.cmeta[chunk]);
@@ -1083,10 +1073,7 @@ void fill_params(const ge_glove *h, GloveParams &p, int32_t iteration) {
     p.bA = h->lay.bA; p.bB = h->lay.bB; p.cstart = h->lay.cstart; p.cmeta = h->lay.cmeta; p.n_chunks = h->n_chunks; p.n_hchunks = h->n_hchunks;
     p.ticket_end = h->n_chunks;
     p.blocked = h->blocked ? 1 : 0; p.hot_enabled = h->cfg.hot_columns != GE_HOT_NONE; p.flush_every = h->flush_every;
-    int64_t domain = h->blocked ? h->n_chunks : h->cfg.nnz;      // what the keyed bijection permutes
-    p.win_m = 0;
-    { const char *e = std::getenv("GE_ORDER_WINDOWS");                 // experiment (tools/r03/window_probe.py)
-      if (e && h->blocked && std::atoi(e) > 1) { const int b = std::atoi(e); p.win_m = (h->n_chunks + b - 1) / b; domain = p.win_m; p.ticket_end = p.win_m * b; } }
+    const int64_t domain = h->blocked ? h->n_chunks : h->cfg.nnz;      // what the keyed bijection permutes
     uint32_t bits = 0;
     while (bits < 31 && ((int64_t)1 << bits) < domain) ++bits;
     p.bij_mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);

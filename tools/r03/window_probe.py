@@ -5,6 +5,9 @@ in the library's order (chunks handed out through the keyed bijection: the worke
 once with GE_ORDER_WINDOWS=B (the bijection permutes inside B consecutive windows of the chunk list: the workers in flight are all in one
 block, so what they stream is V/B records).  Hub columns off and on (with them on, the hub chunks -- the head of the chunk list -- all
 fall into the first window).
+GE_ORDER_WINDOWS lived in a probe build only (commit 99f9383: a branch at the chunk fetch of k_adagrad_runs; it put spill slots under
+the bench instance, which tests/test_kernel_resources.py refuses, and the idea lost, so it was taken out again) -- both legs of
+profiles/r03_window_probe.jsonl ran on that one binary.
    python3 tools/r03/window_probe.py [blocks] [dim]"""
 import json, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
