@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <new>
 #include <type_traits>
 #include <vector>
@@ -1196,6 +1197,20 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     if (const char *pad = std::getenv("GE_RECORD_PAD_LINES")) if (interleave && !packed) h->ds += 16 * std::max(0, std::atoi(pad));   // experiment: record stride + n x 64 B
     if (emb16) h->es = interleave ? 2 * h->ds : D;
 
+    // GE_GLOVE_TIMING=1: where ge_glove_create's time goes, to stderr (host clock; the stream is drained at each lap)
+    struct CreateClock {
+        bool on = std::getenv("GE_GLOVE_TIMING") != nullptr;
+        hipStream_t stream = nullptr;
+        std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+        void lap(const char *what) {
+            if (!on) return;
+            (void)hipStreamSynchronize(stream);
+            const auto n = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[ge_glove_create] %-34s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+            t = n;
+        }
+    } clk;
+    clk.stream = h->stream;
     // every failure below frees what the handle owns so far (ge_glove_destroy walks h->owned)
 #define GE_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ge_status _s = ge::fail(_e == hipErrorOutOfMemory ? GE_ERR_OOM : GE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); ge_glove_destroy(h); return _s; } } while (0)
 
@@ -1289,6 +1304,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
             if (!h->fat) for (int a = 0; a < n_aux; ++a) GE_TRY(h->alloc(&h->tab[BIAST[side][a]], nr));
         }
     }
+    clk.lap("tables (placement search)");
     const size_t nn = (size_t)std::max<int64_t>(N, 1);
     GE_TRY(h->alloc(&h->dcost, 2));
     GE_TRY(h->alloc(&h->djob, (size_t)cfg->threads));
@@ -1361,6 +1377,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
         ge_glove_destroy(h);
         return ge::fail(GE_ERR_ARG, "dim %d too large for deterministic mode", D);
     }
+    clk.lap("epoch layout");
     if (!h->blocked) {
         GE_TRY(h->alloc(&h->dI, nn)); GE_TRY(h->alloc(&h->dJ, nn)); GE_TRY(h->alloc(&h->dX, nn));
         if (N > 0) {
@@ -1422,6 +1439,7 @@ static ge_status ge_glove_create_impl(const ge_glove_cfg *cfg, const int32_t *I,
     GE_TRY(hipStreamSynchronize(h->stream));
     h->rng.s = ge::JavaRandom::jump(s0, (uint64_t)V * (uint64_t)(2 + 2 * D));
 
+    clk.lap("init and the rest");
 #undef GE_TRY
     *out = h;
     return GE_OK;

@@ -14,6 +14,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -110,6 +113,19 @@ void BlockedLayout::release() {
 
 ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const int32_t *J, const float *X,
                                hipStream_t stream, BlockedLayout *out) {
+    struct Clock {           // GE_GLOVE_TIMING=1 (see ge_glove_create)
+        bool on = std::getenv("GE_GLOVE_TIMING") != nullptr;
+        hipStream_t stream = nullptr;
+        std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+        void lap(const char *what) {
+            if (!on) return;
+            (void)hipStreamSynchronize(stream);
+            const auto n = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[ge_glove_create]   layout: %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+            t = n;
+        }
+    } clk;
+    clk.stream = stream;
     const int64_t N = rq.N;
     const int32_t V = rq.V, rb = rq.row_begin, rows = rq.row_end - rq.row_begin;
     Dev tmp;
@@ -132,6 +148,7 @@ ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const 
     GE_HIP(hipMemcpyAsync(cnt.data(), d_col, sizeof(int32_t) * (size_t)V, hipMemcpyDeviceToHost, stream));
     GE_HIP(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, stream));
     GE_HIP(hipStreamSynchronize(stream));
+    clk.lap("upload + column counts");
     if (bad != ~0ull) {
         const int64_t k = (int64_t)bad;
         if (I[k] < rb || I[k] >= rq.row_end) return ge::fail(GE_ERR_ARG, "I[%lld]=%d outside owned rows [%d,%d)", (long long)k, I[k], rb, rq.row_end);
@@ -174,6 +191,7 @@ ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const 
     }
 
     // ---- stable sort: hubs column-major, the rest grouped by row ----
+    clk.lap("hub columns (host)");
     int32_t *d_rank = nullptr; uint32_t *d_key = nullptr, *d_skey = nullptr; int32_t *d_val = nullptr, *d_sval = nullptr;
     GE_HIP(tmp.alloc(&d_rank, (size_t)V));
     GE_HIP(tmp.alloc(&d_key, (size_t)N)); GE_HIP(tmp.alloc(&d_skey, (size_t)N));
@@ -195,6 +213,7 @@ ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const 
     GE_HIP(hipStreamSynchronize(stream));
 
     // ---- chunk table ----
+    clk.lap("sort");
     const int64_t nH = out->hot_nnz, nR = N - nH;
     std::vector<int32_t> cfill, cmeta;                   // per chunk: positions in it, meta
     // H: fixed cuts; a chunk's flush limit is the smallest limit among the columns inside it
@@ -288,6 +307,7 @@ ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const 
     for (int32_t r = 0; r < rows; ++r) if (row_chunk[(size_t)r] >= 0) row_dst[(size_t)r] = cstart[(size_t)row_chunk[(size_t)r]] + row_off[(size_t)r];
 
     // ---- placement ----
+    clk.lap("chunk table (host)");
     int32_t *d_src = nullptr, *d_dst = nullptr;
     GE_HIP(tmp.alloc(&d_src, (size_t)rows)); GE_HIP(tmp.alloc(&d_dst, (size_t)rows));
     GE_HIP(hipMemcpyAsync(d_src, row_src.data(), sizeof(int32_t) * (size_t)rows, hipMemcpyHostToDevice, stream));
@@ -308,6 +328,7 @@ ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const 
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    clk.lap("placement kernel");
     if (e != hipSuccess) {
         out->release();
         return ge::fail(e == hipErrorOutOfMemory ? GE_ERR_OOM : GE_ERR_HIP, "blocked layout build failed: %s", hipGetErrorString(e));
