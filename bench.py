@@ -60,7 +60,7 @@ def parse():
                     help="N=1 only: K > 1 puts the matrix of a K-GPU job on ONE GPU (V = K x rows-per-gpu, the K ranks' shards concatenated: "
                          "8 = BASELINE C4 at its own size, 5 M vertices / 0.86 G nonzeros); a recorded profile leg, not the default workload")
     ap.add_argument("--hub-segments", type=int, default=0,
-                    help="N>1: small exchanges of the hub rows per epoch (ge_sync_epoch); 0 = the library's default (the number of ranks, at least 8), -1 = none (one exchange per epoch for every row)")
+                    help="N>1: small exchanges of the hub rows per epoch (ge_sync_epoch); 0 = the library's choice (by the busiest column; at least max(8, ranks)), -1 = none (one exchange per epoch for every row)")
     ap.add_argument("--no-other-form", action="store_true", help="N>1: do not time the other exchange form behind the quoted region")
     ap.add_argument("--accum-sync-every", type=int, default=4, help="every how many context syncs the AdaGrad accumulators are reconciled too (N>1)")
     return ap.parse_args()
@@ -222,6 +222,7 @@ def main():
         raise SystemExit("bench.py --gpus N: the context exchange (which deltas add, which average) is defined for adagrad only")
     if world > 1:
         sync = parallel.context_sync_for(opt, torch.device("cuda", local_rank), lazy_every=args.accum_sync_every, wire=args.wire)
+        hub_plan = sync.hub_plan(max(args.hub_segments, 0))
 
     def step(it, form=None):
         # N > 1: ge_sync_epoch -- the rank's epoch in segments, the hub rows of the context side reconciled behind each
@@ -270,7 +271,7 @@ def main():
             ms, nl = opt.last_kernel_ms()
             k_ms2 += ms; nl2 += nl
         fence()
-        other = {"exchange": form2, "dt": time.perf_counter() - t2, "costs": costs2, "kernel_ms": k_ms2 / max(nl2, 1)}
+        other = {"exchange": form2, "dt": time.perf_counter() - t2, "costs": costs2, "kernel_ms": k_ms2 / max(args.steps, 1)}
 
     # what THIS box's memory system gives a plain device-to-device copy (1 GiB, read + written bytes), right after the timed
     # region: boxes of the pool differ by 10-15 % in the epoch time of one binary, and this says which kind ran
@@ -283,7 +284,7 @@ def main():
 
     total_updates = n_local * args.steps
     n_global = n_local
-    kernel_ms_max = kernel_ms / max(launches, 1)
+    kernel_ms_max = kernel_ms / max(args.steps, 1)            # this rank's epoch kernel(s), own time, per step (a segmented epoch: its launches summed)
     if dist is not None:
         t = torch.tensor([dt, kernel_ms_max, other["dt"] if other else 0.0, other["kernel_ms"] if other else 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,8 +321,13 @@ def main():
         read_b, write_b = (16 * D + 28, 16 * D + 16) if args.opt == "adagrad" else (24 * D + 36, 24 * D + 24)
         if args.dtype == "bf16":
             read_b, write_b = 12 * D + 28, 12 * D + 16
-        avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-        sched = info["schedule_bytes"]
+        # one step = one epoch = `launches_per_step` launches of the update kernel (1; a sharded run whose epoch is cut in segments: that many);
+        # the bytes of the schedule and the updates are per EPOCH, so the per-launch figures below are the epoch's divided by the launches
+        launches_per_step = max(launches, 1) / max(args.steps, 1)
+        epoch_kernel_s = kernel_ms / max(args.steps, 1) / 1e3
+        avg_kernel_s = epoch_kernel_s / launches_per_step
+        sched = info["schedule_bytes"] / launches_per_step
+        n_launch = n_local / launches_per_step
         ach = sched / avg_kernel_s / 1e9                                  # GB/s, rank 0's kernel
         out = {
             "metric": "GloVe pair-updates/sec at dim=%d" % D,
@@ -339,7 +345,7 @@ def main():
                        "parallelism": "rows sharded x%d, context replicated + delta all-reduce every %d step(s) (rows summed, biases averaged, accumulators summed every %d syncs, %s on the wire, %s; hub rows reconciled %s per epoch in fp32)"
                                       % (world, args.sync_every, args.accum_sync_every, args.wire,
                                          "overlapped with the next epoch, %d wavefront slots reserved" % args.reserve_waves if args.exchange == "overlap" else "synchronous",
-                                         ("%d times" % args.hub_segments) if args.hub_segments > 0 else ("max(8, ranks) times" if args.hub_segments == 0 else "never"))
+                                         ("never" if args.hub_segments < 0 else "%d times, %s" % (hub_plan["exchanges"], "beside the running epoch kernel (%d rows live)" % hub_plan["live_rows"] if hub_plan["live"] else "between segments of the epoch")))
                                       if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                          "traffic": traffic,
@@ -348,17 +354,17 @@ def main():
                          # time divided into them below is THIS run's
                          "traffic_source": "profiles/traffic.json (committed rocprofv3 --pmc passes of this kernel instance, workload and layout)" if traffic else None,
                          "frac_traffic": (traffic / avg_kernel_s / 1e9 / 8000.0) if traffic else None,
-                         "kernel": kernel, "kernel_ms": avg_kernel_s * 1e3,
-                         "schedule_bytes_per_launch": sched, "schedule_bytes_per_update": sched / max(n_local, 1),
-                         "runs_per_launch": info["runs"],
+                         "kernel": kernel, "kernel_ms": avg_kernel_s * 1e3, "launches_per_step": launches_per_step,
+                         "schedule_bytes_per_launch": sched, "schedule_bytes_per_update": sched / max(n_launch, 1),
+                         "runs_per_launch": info["runs"] / launches_per_step,
                          "frac_of_measured_copy_ceiling": ach / 6290.0,           # float4 copy, MI355X_MICROARCH.md
                          "box_copy_GBps": box_copy,                # ge_copy_bandwidth on this box, right after the timed region
-                         "kernel_updates_per_s": n_local / avg_kernel_s,
+                         "kernel_updates_per_s": n_launch / avg_kernel_s,
                          # what SURVEY.md 8(d) counts: every update moves both row pairs through HBM (this kernel keeps one in registers)
                          "naive_schedule": {"bytes_per_update": {"read": read_b, "write": write_b},
-                                            "bytes_per_launch": n_local * (read_b + write_b),
-                                            "equivalent_GBps": n_local * (read_b + write_b) / avg_kernel_s / 1e9,
-                                            "updates_per_s_over_read_roofline_rate": (n_local / avg_kernel_s) / (8e12 / read_b)}},
+                                            "bytes_per_launch": n_launch * (read_b + write_b),
+                                            "equivalent_GBps": n_launch * (read_b + write_b) / avg_kernel_s / 1e9,
+                                            "updates_per_s_over_read_roofline_rate": (n_launch / avg_kernel_s) / (8e12 / read_b)}},
             "mean_cost_first_last": [costs[0] / n_global, costs[-1] / n_global],
             # N > 1: every rank's job costs summed over all nonzeros of the job, per step (warm-up steps first)
             "mean_cost_per_step": [c / n_global for c in costs],
@@ -368,7 +374,7 @@ def main():
             "gen_seconds": t_gen, "create_seconds": t_create,
         }
         if world > 1:
-            out["exchange"] = {"form": args.exchange, "kernel_ms_max_over_ranks": kernel_ms_max,
+            out["exchange"] = {"form": args.exchange, "hub_rows": dict(hub_plan, still_live=sync.hub_plan(max(args.hub_segments, 0))["live"]), "kernel_ms_max_over_ranks": kernel_ms_max,
                                "ms_per_step_minus_kernel_ms": dt / args.steps * 1e3 - kernel_ms_max}
             if other:
                 out["exchange"]["other_form"] = {"form": other["exchange"], "value": total_updates / other["dt"], "ms_per_step": other["dt"] / args.steps * 1e3,

@@ -49,6 +49,7 @@ struct BlockedLayout {
     int64_t n_runs = 0;              // runs per epoch: times a resident row (+ its accumulator row) is loaded and published
     std::vector<int32_t> hubs;       // the hub columns, ascending
     std::vector<int32_t> heavy;      // columns with count >= max(256, N / 20 480), ascending: what a sharded run reconciles inside an epoch
+    std::vector<int32_t> heavy_count; // their nonzero counts on this handle
     std::vector<int32_t> hub_index;  // [V] dense hub index or -1 (want_hub_index)
     int32_t n_hub = 0;
     void release();                  // frees the device arrays

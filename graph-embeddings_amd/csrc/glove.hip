@@ -1020,6 +1020,8 @@ struct ge_glove {
     float *hub32 = nullptr;           // bf16 build: fp32 master rows of the hub columns
     int32_t *dhub_index = nullptr;
     unsigned long long seg_ticket[64] = {};   // first ticket of each segment of a segmented epoch (source of small async copies)
+    hipEvent_t seg_ev[128] = {};              // a segmented epoch: events around every segment's launch (created on first use), so that
+    int32_t seg_timed = 0;                    //   last_ms is the kernels' own time, the exchanges between them not included
     std::vector<int32_t> host_hub_index;
     int32_t n_hub = 0;
     std::vector<int32_t> host_key;    // general order: sort key per nonzero (what the kernel stages as `key`)
@@ -1747,7 +1749,10 @@ namespace ge {
 // A Hogwild epoch in `nseg` launches (ge_sync_epoch: the hub rows of a sharded run are reconciled between them).  The chunks of
 // the epoch are handed out by ticket through a keyed bijection, so tickets [n seg / nseg, n (seg + 1) / nseg) are a random nseg-th
 // of the epoch; the cost accumulates on the device over the segments.  Nothing here blocks the host: glove_epoch_finish does.
-ge_status glove_epoch_segment(ge_glove *h, int32_t iteration, int32_t seg, int32_t nseg) {
+// leave_blocks: workgroups NOT launched (their wavefront slots stay free for kernels running beside the epoch: the live hub-row exchange
+// of a sharded run); after_reset: recorded once the ticket counter holds this segment's first ticket (a host that watches the counter
+// waits for it, so that it never reads the previous epoch's value).
+ge_status glove_epoch_segment(ge_glove *h, int32_t iteration, int32_t seg, int32_t nseg, int32_t leave_blocks, hipEvent_t after_reset) {
     ge_status st = check_handle(h);
     if (st != GE_OK) return st;
     if (h->cfg.mode != GE_MODE_HOGWILD || h->cfg.shuffle == GE_SHUFFLE_JAVA) return ge::fail(GE_ERR_STATE, "a segmented epoch needs a GE_MODE_HOGWILD handle with a device-side order");
@@ -1760,25 +1765,47 @@ ge_status glove_epoch_segment(ge_glove *h, int32_t iteration, int32_t seg, int32
         GE_HIP(hipMemsetAsync(h->dcost, 0, 2 * sizeof(double), h->stream));
         GE_HIP(hipEventRecord(h->ev0, h->stream));
         h->last_launches = 0;
+        h->seg_timed = 0;
     }
     if (end > begin) {
         h->seg_ticket[seg] = (unsigned long long)begin;
         GE_HIP(hipMemcpyAsync(p.queue, &h->seg_ticket[seg], sizeof(unsigned long long), hipMemcpyHostToDevice, h->stream));
         p.ticket_end = end;
-        hipLaunchKernelGGL(h->hw_fn, dim3(h->hw_blocks), dim3(256), 0, h->stream, p, (int32_t)h->hw_workers);
+        if (after_reset) GE_HIP(hipEventRecord(after_reset, h->stream));
+        hipEvent_t *ev = &h->seg_ev[2 * h->seg_timed];
+        for (int k = 0; k < 2; ++k) if (!ev[k]) GE_HIP(hipEventCreate(&ev[k]));
+        GE_HIP(hipEventRecord(ev[0], h->stream));
+        hipLaunchKernelGGL(h->hw_fn, dim3((unsigned)std::max(1, h->hw_blocks - std::max(0, leave_blocks))), dim3(256), 0, h->stream, p, (int32_t)h->hw_workers);
+        GE_HIP(hipEventRecord(ev[1], h->stream));
+        ++h->seg_timed;
         ++h->last_launches;
         GE_HIP(hipGetLastError());
     }
+    else if (after_reset) GE_HIP(hipEventRecord(after_reset, h->stream));
     if (seg == nseg - 1) GE_HIP(hipEventRecord(h->ev1, h->stream));
     return GE_OK;
 }
+// the epoch's ticket counter (device memory; tickets [0, *tickets) are the epoch's chunks) and the event behind the last launch
+ge_status glove_epoch_progress(ge_glove *h, const unsigned long long **counter, int64_t *tickets, hipEvent_t *done) {
+    ge_status st = check_handle(h);
+    if (st != GE_OK) return st;
+    if (counter) *counter = reinterpret_cast<const unsigned long long *>(h->dcost + 1);
+    if (tickets) *tickets = h->cfg.nnz > 0 ? h->n_chunks : 0;
+    if (done) *done = h->ev1;
+    return GE_OK;
+}
+// the columns this handle's epoch kernel treats as hubs (resident runs that publish the row and its accumulator row by float atomics)
+const std::vector<int32_t> *glove_kernel_hubs(const ge_glove *h) { return (h && h->blocked && h->cfg.hot_columns != GE_HOT_NONE) ? &h->lay.hubs : nullptr; }
+const std::vector<int32_t> *glove_hub_counts(const ge_glove *h) { return h ? &h->lay.heavy_count : nullptr; }
 ge_status glove_epoch_finish(ge_glove *h, double *cost_sum) {
     ge_status st = check_handle(h);
     if (st != GE_OK) return st;
     double total = 0.0;
     GE_HIP(hipMemcpyAsync(&total, h->dcost, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     GE_HIP(hipStreamSynchronize(h->stream));
-    GE_HIP(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));      // first launch to last, the exchanges between them included
+    // ge_glove_last_kernel_ms: the launches' own time summed (what the caller's exchanges between them took is the caller's to time)
+    h->last_ms = 0.0f;
+    for (int32_t k = 0; k < h->seg_timed; ++k) { float ms = 0.0f; GE_HIP(hipEventElapsedTime(&ms, h->seg_ev[2 * k], h->seg_ev[2 * k + 1])); h->last_ms += ms; }
     if (cost_sum) *cost_sum = total;
     return GE_OK;
 }
@@ -1796,6 +1823,7 @@ extern "C" {
 void ge_glove_destroy(ge_glove *h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
+    for (hipEvent_t e : h->seg_ev) if (e) (void)hipEventDestroy(e);
     for (void *q : h->owned) (void)hipFree(q);
     h->lay.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);

@@ -159,9 +159,22 @@ ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const 
     std::vector<int32_t> hub_rank((size_t)V, -1);
     std::vector<int32_t> hubs;                     // hub columns, ascending
     out->hot_cols = 0; out->hot_nnz = 0; out->hot_threshold = 0; out->n_runs = 0;
+    // The columns a SHARDED run reconciles inside the epoch (ge_sync_epoch): busy enough that a rank pushes them hard within one epoch.
+    // Independent of this handle's worker count (that is about concurrency INSIDE the GPU): count >= N / 20 480 -- what the hub rule
+    // gives a full device, 0.25 N / 5 120 -- and at least 256.
+    int64_t heavy_thr;
+    {
+        int64_t div = 20480, floor_n = 256;
+        if (const char *e = std::getenv("GE_SYNC_HEAVY_DIV")) div = std::max<int64_t>(1, std::atoll(e));          // experiments (tools/r03/heavy_probe.sh)
+        if (const char *e = std::getenv("GE_SYNC_HEAVY_MIN")) floor_n = std::max<int64_t>(1, std::atoll(e));
+        heavy_thr = std::max<int64_t>(floor_n, N / div);
+    }
     if (N > 0 && rq.hot_columns != GE_HOT_NONE) {
-        const int64_t thr = rq.hot_columns == GE_HOT_ALL ? 0
-                          : std::max<int64_t>(2, (int64_t)std::ceil(rq.hot_theta * (double)N / (double)std::max(rq.workers, 1)));
+        int64_t thr = rq.hot_columns == GE_HOT_ALL ? 0
+                    : std::max<int64_t>(2, (int64_t)std::ceil(rq.hot_theta * (double)N / (double)std::max(rq.workers, 1)));
+        // a shard of a larger run: every column the exchange inside the epoch covers is a hub HERE too, i.e. moved by atomic adds only,
+        // so that the other ranks' deltas can be added to it while the epoch kernel runs (the live exchange, sync.hip)
+        if (rq.row_end - rq.row_begin < V) thr = std::min(thr, heavy_thr);
         for (int32_t v = 0; v < V; ++v)
             if (cnt[(size_t)v] >= thr && cnt[(size_t)v] > 0) { hub_rank[(size_t)v] = (int32_t)hubs.size(); hubs.push_back(v); out->hot_nnz += cnt[(size_t)v]; }
         out->hot_cols = (int32_t)hubs.size();
@@ -181,14 +194,8 @@ ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const 
     for (int32_t c : hubs) out->flush_min = std::min(out->flush_min, flush_limit(c));
     if (rq.want_hub_index) { out->hub_index = hub_rank; out->n_hub = n_hub; }
     out->hubs = hubs;
-    // The columns a SHARDED run reconciles inside the epoch (ge_sync_epoch): busy enough that a rank pushes them hard within one epoch.
-    // Independent of this handle's worker count and of cfg.hot_columns (those are about concurrency INSIDE the GPU): count >= N / 20 480
-    // -- what the hub rule gives a full device, 0.25 N / 5 120 -- and at least 256.
-    out->heavy.clear();
-    {
-        const int64_t thr = std::max<int64_t>(256, N / 20480);
-        for (int32_t v = 0; v < V; ++v) if (cnt[(size_t)v] >= thr) out->heavy.push_back(v);
-    }
+    out->heavy.clear(); out->heavy_count.clear();
+    for (int32_t v = 0; v < V; ++v) if (cnt[(size_t)v] >= heavy_thr) { out->heavy.push_back(v); out->heavy_count.push_back(cnt[(size_t)v]); }
 
     // ---- stable sort: hubs column-major, the rest grouped by row ----
     clk.lap("hub columns (host)");

@@ -29,14 +29,19 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <chrono>
 #include <vector>
 
 // glove.hip
 namespace ge {
 ge_status glove_sync_view(ge_glove *h, int32_t *opt, int32_t *mode, void **stream, int32_t *device);
-ge_status glove_epoch_segment(ge_glove *h, int32_t iteration, int32_t seg, int32_t nseg);
+ge_status glove_epoch_segment(ge_glove *h, int32_t iteration, int32_t seg, int32_t nseg, int32_t leave_blocks, hipEvent_t after_reset);
 ge_status glove_epoch_finish(ge_glove *h, double *cost_sum);
+ge_status glove_epoch_progress(ge_glove *h, const unsigned long long **counter, int64_t *tickets, hipEvent_t *done);
 const std::vector<int32_t> *glove_hub_columns(const ge_glove *h);
+const std::vector<int32_t> *glove_hub_counts(const ge_glove *h);
+const std::vector<int32_t> *glove_kernel_hubs(const ge_glove *h);
 }
 
 namespace {
@@ -240,9 +245,51 @@ __global__ __launch_bounds__(256) void k_hub_land(const int32_t *__restrict__ li
         bias_base[v] = c; bias[v * bias_stride] = c;
     }
 }
-__global__ void k_mark(const int32_t *list, int32_t n, float *flags) {
+__global__ void k_mark(const int32_t *list, const int32_t *value, int32_t n, float *flags) {       // value == nullptr: 1
     const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) flags[list[k]] = 1.0f;
+    if (k < n) flags[list[k]] = value ? (float)value[k] : 1.0f;
+}
+
+// ---- the LIVE exchange of hub rows: while the epoch kernel runs ----------------------------------------------------------------
+// The rows of `list` are hub columns of the epoch kernel on EVERY rank: the kernel moves them (and their accumulator rows) by float
+// atomic adds of deltas only, never by stores -- so another adder is safe beside it.  take: own = row - base (the rank's moves since the
+// last take, read with agent-coherent loads: the atomics execute at the memory side) -> buf and own; [all-reduce of buf]; land: the OTHER
+// ranks' moves, buf - own, are ADDED to the row atomically and base += buf (base is touched by these two kernels only).  After a land the
+// next take finds exactly the rank's moves since this take: (row + others + later) - (base + sum) = later.  Nothing here waits for the
+// epoch kernel and nothing the epoch kernel does is lost; the scalars of the rows (bias, its accumulator: last-writer-wins stores in the
+// kernel) are left to the exact exchange at the end of the epoch.
+__global__ __launch_bounds__(256) void k_live_take(const int32_t *__restrict__ list, int32_t H, int32_t D,
+                                                   const float *rows, int64_t rows_stride, const float *__restrict__ rows_base,
+                                                   const float *acc, int64_t acc_stride, const float *__restrict__ acc_base,
+                                                   float *__restrict__ buf, float *__restrict__ own) {
+    const int lane = threadIdx.x & 63;
+    const int32_t h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= H) return;
+    const int64_t v = list[h];
+    for (int32_t d = lane; d < D; d += 64) {
+        const float r = __hip_atomic_load(rows + v * rows_stride + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float a = __hip_atomic_load(acc + v * acc_stride + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float dr = r - rows_base[v * D + d], da = a - acc_base[v * D + d];
+        const int64_t k = (int64_t)h * D + d;
+        buf[k] = dr; own[k] = dr;
+        buf[(int64_t)H * D + k] = da; own[(int64_t)H * D + k] = da;
+    }
+}
+__global__ __launch_bounds__(256) void k_live_land(const int32_t *__restrict__ list, int32_t H, int32_t D,
+                                                   float *rows, int64_t rows_stride, float *__restrict__ rows_base,
+                                                   float *acc, int64_t acc_stride, float *__restrict__ acc_base,
+                                                   const float *__restrict__ buf, const float *__restrict__ own) {
+    const int lane = threadIdx.x & 63;
+    const int32_t h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= H) return;
+    const int64_t v = list[h];
+    for (int32_t d = lane; d < D; d += 64) {
+        const int64_t k = (int64_t)h * D + d, ka = (int64_t)H * D + k;
+        unsafeAtomicAdd(rows + v * rows_stride + d, buf[k] - own[k]);
+        unsafeAtomicAdd(acc + v * acc_stride + d, buf[ka] - own[ka]);
+        rows_base[v * D + d] += buf[k];
+        acc_base[v * D + d] += buf[ka];
+    }
 }
 
 // dense <-> strided copies (base initialisation, replicate)
@@ -318,6 +365,7 @@ struct ge_local_group {
     int world = 0;
     std::mutex m; std::condition_variable cv; int arrived = 0; unsigned long generation = 0;
     bool aborted = false;                                  // a rank failed: nobody may wait for it any more
+    int timeout_s = [] { const char *e = std::getenv("GE_LOCAL_GROUP_TIMEOUT_S"); const int v = e ? std::atoi(e) : 0; return v > 0 ? v : 600; }();
     std::vector<std::vector<unsigned char>> stage;        // one host buffer per rank
     // false: the group was aborted (before or while waiting); the caller returns GE_ERR_STATE
     bool barrier() {
@@ -325,7 +373,10 @@ struct ge_local_group {
         if (aborted) return false;
         const unsigned long g = generation;
         if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(lk, [&] { return generation != g || aborted; });
+        else if (!cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return generation != g || aborted; })) {
+            aborted = true; cv.notify_all();              // a rank that never comes (stuck, or gone without ge_local_group_abort) must not hold the others for ever
+            std::fprintf(stderr, "geglove: a rank of the local group did not reach an exchange within %d s; the group is aborted\n", timeout_s);
+        }
         return !aborted;
     }
     void abort() { std::lock_guard<std::mutex> lk(m); aborted = true; cv.notify_all(); }
@@ -350,6 +401,14 @@ struct ge_sync {
     uint32_t seed = 0x5EED;
     int32_t *hub_list = nullptr; int32_t n_hub = 0;       // the union of the ranks' hub columns (ascending), on the device
     float *hub_buf = nullptr;                              // [n_hub x (2 D + 3)] fp32: the hub rows' deltas of one small exchange
+    float hub_top_count = 0.0f;                            // nonzeros of the busiest hub column in the whole job: sets how often the hub rows are exchanged per epoch
+    int32_t *live_list = nullptr; int32_t n_live = 0;     // the columns that are hubs of the epoch kernel on EVERY rank (fp32 rows): exchanged while the kernel runs
+    float *live_buf = nullptr, *live_own = nullptr;        // [n_live x 2 D] each
+    hipEvent_t ev_reset = nullptr;                         // the epoch's ticket counter holds its first ticket
+    unsigned long long *progress = nullptr;                // pinned host word the ticket counter is copied into
+    bool live = false;                                     // ge_sync_epoch exchanges the live rows beside the epoch kernel (else: the epoch in segments)
+    int32_t late_streak = 0;                               // consecutive live epochs in which some rank's exchanges fell behind
+    int64_t live_epochs = 0, live_late = 0;                // epochs run live, and exchanges in them that were issued a whole interval late
     ge_context_layout lay{};
     template <typename T> hipError_t alloc(T **out, size_t n) {
         hipError_t e = hipMalloc((void **)out, sizeof(T) * std::max<size_t>(n, 1));
@@ -361,7 +420,9 @@ struct ge_sync {
 namespace {
 
 // sum of every rank's device buffer, in rank order, back into each rank's buffer (blocking; the caller's stream is idle)
-ge_status local_allreduce(ge_local_group *g, int rank, void *buf, int64_t count, int32_t dtype, bool bcast, int src) {
+// st: the stream the device copies are ordered on (nullptr: plain blocking copies -- they wait for the null stream, i.e. for an epoch kernel
+// running there; the live exchange passes its own stream)
+ge_status local_allreduce(ge_local_group *g, int rank, void *buf, int64_t count, int32_t dtype, bool bcast, int src, hipStream_t st = nullptr) {
     const size_t bytes = (size_t)count * (dtype == GE_DTYPE_BF16 ? 2 : dtype == 2 ? 8 : 4);       // dtype 2: host doubles (scalars)
     // a rank whose copy fails still reaches the barriers (its peers would wait for ever otherwise) and aborts the group
     static const char *gone = "ge_local_group: another rank of the group failed";
@@ -369,6 +430,7 @@ ge_status local_allreduce(ge_local_group *g, int rank, void *buf, int64_t count,
     mine.resize(bytes);
     hipError_t he = hipSuccess;
     if (dtype == 2) std::memcpy(mine.data(), buf, bytes);
+    else if (st) { he = hipMemcpyAsync(mine.data(), buf, bytes, hipMemcpyDeviceToHost, st); if (he == hipSuccess) he = hipStreamSynchronize(st); }
     else he = hipMemcpy(mine.data(), buf, bytes, hipMemcpyDeviceToHost);
     if (he != hipSuccess) { g->abort(); return ge::fail(GE_ERR_HIP, "local all-reduce: copy to the host failed: %s", hipGetErrorString(he)); }
     if (!g->barrier()) return ge::fail(GE_ERR_STATE, "%s", gone);
@@ -395,7 +457,8 @@ ge_status local_allreduce(ge_local_group *g, int rank, void *buf, int64_t count,
     }
     if (!g->barrier()) return ge::fail(GE_ERR_STATE, "%s", gone);      // every rank has read the stage
     if (dtype == 2) std::memcpy(buf, out.data(), bytes);
-    else if ((he = hipMemcpy(buf, out.data(), bytes, hipMemcpyHostToDevice)) != hipSuccess) {
+    else if ((he = st ? hipMemcpyAsync(buf, out.data(), bytes, hipMemcpyHostToDevice, st) : hipMemcpy(buf, out.data(), bytes, hipMemcpyHostToDevice)) != hipSuccess
+             || (st && (he = hipStreamSynchronize(st)) != hipSuccess)) {
         g->abort();
         return ge::fail(GE_ERR_HIP, "local all-reduce: copy to the device failed: %s", hipGetErrorString(he));
     }
@@ -534,6 +597,44 @@ ge_status hub_exchange(ge_sync *s) {
     return GE_OK;
 }
 
+// one live exchange (k_live_take / all-reduce / k_live_land), everything on the hub stream: safe while the epoch kernel runs on the handle's
+ge_status live_exchange(ge_sync *s) {
+    if (s->n_live == 0) return GE_OK;
+    const Entry &er = s->ent[0], &ea = s->ent[2];
+    const int32_t H = s->n_live, D = s->lay.dim;
+    const dim3 g((unsigned)((H + 3) / 4)), b(256);
+    hipLaunchKernelGGL(k_live_take, g, b, 0, s->hub_side, (const int32_t *)s->live_list, H, D, (const float *)er.table, er.t_stride, (const float *)er.base,
+                       (const float *)ea.table, ea.t_stride, (const float *)ea.base, s->live_buf, s->live_own);
+    GE_HIP(hipGetLastError());
+    const int64_t n = (int64_t)H * 2 * D;
+    if (s->loop) {
+        GE_HIP(hipStreamSynchronize(s->hub_side));
+        ge_status st = local_allreduce(s->loop, s->cfg.rank, s->live_buf, n, GE_DTYPE_F32, false, 0, s->hub_side);
+        if (st != GE_OK) return st;
+    } else GE_NCCL(rccl().AllReduce(s->live_buf, s->live_buf, (size_t)n, ncclFloat32, ncclSum, s->hub_comm, s->hub_side));
+    hipLaunchKernelGGL(k_live_land, g, b, 0, s->hub_side, (const int32_t *)s->live_list, H, D, er.table, er.t_stride, er.base, ea.table, ea.t_stride, ea.base,
+                       (const float *)s->live_buf, (const float *)s->live_own);
+    GE_HIP(hipGetLastError());
+    return GE_OK;
+}
+
+// how ge_sync_epoch reconciles the hub rows: how often per epoch, and whether beside the running kernel (live) or between segments of it.
+// The busiest column decides.  Measured on the bench's matrix split over four ranks (625 k vertices, 103 M nonzeros, the busiest column
+// in every row: 625 k nonzeros): 8 exchanges per epoch -- 78 k updates of that row between two exchanges, all ranks together --
+// leave the single-GPU cost trajectory in epochs 3 to 5 and may not come back, 16 follow it within 2 %, 24 and more exactly.  So: one exchange
+// per 32 768 updates of the busiest column (20 there), at least max(8, ranks); a live exchange costs the epoch nothing and may come 128
+// times per epoch, a segment costs a kernel boundary (0.18 ms at the bench size) plus the exchange and is capped at 64.
+void hub_plan(const ge_sync *s, int32_t segments, bool *live, int32_t *exchanges) {
+    const bool lv = s->live && s->n_live > 0;
+    const int32_t cap = lv ? 128 : 64;
+    int32_t n = segments;
+    if (n <= 0) {
+        n = (int32_t)std::min<double>(cap, std::ceil((double)s->hub_top_count / 32768.0));
+        n = std::max(n, std::max(8, s->cfg.world));
+    }
+    *live = lv; *exchanges = std::min(n, cap);
+}
+
 ge_status turn(ge_sync *s, bool land, bool take, bool everything) {
     if (!s) return ge::fail(GE_ERR_ARG, "null ge_sync handle");
     if (s->cfg.world == 1) return GE_OK;
@@ -625,6 +726,8 @@ void ge_sync_destroy(ge_sync *s) {
     if (s->hub_side) (void)hipStreamSynchronize(s->hub_side);
     if (s->hub_comm && s->hub_comm != s->comm && rccl().ok) (void)rccl().CommDestroy(s->hub_comm);
     if (s->comm && rccl().ok) (void)rccl().CommDestroy(s->comm);
+    if (s->ev_reset) (void)hipEventDestroy(s->ev_reset);
+    if (s->progress) (void)hipHostFree(s->progress);
     if (s->ev_hub_a) (void)hipEventDestroy(s->ev_hub_a);
     if (s->ev_hub_b) (void)hipEventDestroy(s->ev_hub_b);
     if (s->hub_side) (void)hipStreamDestroy(s->hub_side);
@@ -718,17 +821,22 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
         // vector is summed).  A bf16 handle keeps the fp32 masters of ITS hubs, and a column that is a
         // hub on one rank and an ordinary bf16 row on another is written back as each rank stores it (k_hub_land).
         {
-            const std::vector<int32_t> *mine = ge::glove_hub_columns(h);
-            float *flags = nullptr; int32_t *tmp = nullptr;
+            const std::vector<int32_t> *mine = ge::glove_hub_columns(h), *mine_n = ge::glove_hub_counts(h);
+            float *flags = nullptr; int32_t *tmp = nullptr, *tmp_n = nullptr;
             GE_TRYS(hipMalloc((void **)&flags, sizeof(float) * (size_t)std::max<int64_t>(V, 1)));
             s->owned.push_back(flags);
+            // pass 1: every rank writes the nonzero counts of ITS busy columns, the vector is summed: > 0 = in the union, the value = the
+            // column's nonzeros in the whole job (over the ranks that flagged it)
             GE_TRYS(hipMemsetAsync(flags, 0, sizeof(float) * (size_t)V, s->main));
             const int32_t nm = mine ? (int32_t)mine->size() : 0;
             if (nm > 0) {
                 GE_TRYS(hipMalloc((void **)&tmp, sizeof(int32_t) * (size_t)nm));
                 s->owned.push_back(tmp);
+                GE_TRYS(hipMalloc((void **)&tmp_n, sizeof(int32_t) * (size_t)nm));
+                s->owned.push_back(tmp_n);
                 GE_TRYS(hipMemcpyAsync(tmp, mine->data(), sizeof(int32_t) * (size_t)nm, hipMemcpyHostToDevice, s->main));
-                hipLaunchKernelGGL(k_mark, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s->main, (const int32_t *)tmp, nm, flags);
+                GE_TRYS(hipMemcpyAsync(tmp_n, mine_n->data(), sizeof(int32_t) * (size_t)nm, hipMemcpyHostToDevice, s->main));
+                hipLaunchKernelGGL(k_mark, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, s->main, (const int32_t *)tmp, (const int32_t *)tmp_n, nm, flags);
             }
             st = allreduce_f32_small(s, flags, V);
             if (st != GE_OK) { ge_sync_destroy(s); return st; }
@@ -736,12 +844,41 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
             GE_TRYS(hipMemcpyAsync(hf.data(), flags, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s->main));
             GE_TRYS(hipStreamSynchronize(s->main));
             std::vector<int32_t> all;
-            for (int64_t v = 0; v < V; ++v) if (hf[(size_t)v] > 0.0f) all.push_back((int32_t)v);
+            for (int64_t v = 0; v < V; ++v) if (hf[(size_t)v] > 0.0f) { all.push_back((int32_t)v); s->hub_top_count = std::max(s->hub_top_count, hf[(size_t)v]); }
             s->n_hub = (int32_t)all.size();
             if (s->n_hub > 0) {
                 GE_TRYS(s->alloc(&s->hub_list, (size_t)s->n_hub));
                 GE_TRYS(hipMemcpy(s->hub_list, all.data(), sizeof(int32_t) * all.size(), hipMemcpyHostToDevice));
                 GE_TRYS(s->alloc(&s->hub_buf, (size_t)s->n_hub * (size_t)(2 * D + 3)));
+            }
+            // The live form (fp32 rows; RCCL or a local group -- a host callback cannot run beside the epoch kernel): the hub rows are exchanged
+            // while the epoch kernel runs, which is safe for rows the kernel moves by atomic adds only: its hub columns.  A sharded handle's
+            // hub rule includes every column that is busy on the rank itself (glove_layout.hip), so what is not a hub here is a column at
+            // the threshold that another rank counted in: a delta landing on such a row can fall into a worker's load-update-store and be
+            // overwritten -- that rank then reports the loss with its next take and the replicas stay consistent (one exchange's worth
+            // of the others' moves on that row is dropped, what Hogwild does to ordinary rows all the time).  Every rank must find its own busy
+            // columns among its kernel's hubs (not so with hot columns switched off): they agree by a one-word all-reduce.
+            const char *mode_env = std::getenv("GE_SYNC_EPOCH");                     // "segments": the epoch in segments, as before the live exchange
+            const std::vector<int32_t> *kh = ge::glove_kernel_hubs(h);
+            bool mine_ok = kh != nullptr;
+            if (mine_ok && mine) for (int32_t v : *mine) if (!std::binary_search(kh->begin(), kh->end(), v)) { mine_ok = false; break; }
+            const bool can = s->lay.dtype != GE_DTYPE_BF16 && !s->tr.start && !(mode_env && std::strcmp(mode_env, "segments") == 0) && s->n_hub > 0;
+            const float vote = (can && mine_ok) ? 0.0f : 1.0f;
+            GE_TRYS(hipMemcpyAsync(flags, &vote, sizeof(float), hipMemcpyHostToDevice, s->main));
+            GE_TRYS(hipStreamSynchronize(s->main));
+            st = allreduce_f32_small(s, flags, 1);
+            if (st != GE_OK) { ge_sync_destroy(s); return st; }
+            float against = 1.0f;
+            GE_TRYS(hipMemcpyAsync(&against, flags, sizeof(float), hipMemcpyDeviceToHost, s->main));
+            GE_TRYS(hipStreamSynchronize(s->main));
+            if (against == 0.0f) {
+                s->live_list = s->hub_list; s->n_live = s->n_hub;
+                GE_TRYS(s->alloc(&s->live_buf, (size_t)s->n_live * (size_t)(2 * D)));
+                GE_TRYS(s->alloc(&s->live_own, (size_t)s->n_live * (size_t)(2 * D)));
+                if (!s->hub_side) GE_TRYS(hipStreamCreateWithFlags(&s->hub_side, hipStreamNonBlocking));      // (a local group has no RCCL streams)
+                GE_TRYS(hipEventCreateWithFlags(&s->ev_reset, hipEventDisableTiming));
+                GE_TRYS(hipHostMalloc((void **)&s->progress, sizeof(unsigned long long)));
+                s->live = true;
             }
         }
     }
@@ -770,13 +907,72 @@ static ge_status ge_sync_epoch_impl(ge_sync *s, int32_t iteration, int32_t segme
     if (!s) return ge::fail(GE_ERR_ARG, "null ge_sync handle");
     if (s->cfg.world == 1 || s->n_hub == 0) return ge_glove_epoch(s->h, iteration, cost_sum);
     GE_HIP(hipSetDevice(s->device));
-    const int32_t S = std::min(64, segments > 0 ? segments : std::max(8, s->cfg.world));
-    for (int32_t seg = 0; seg < S; ++seg) {
-        ge_status st = ge::glove_epoch_segment(s->h, iteration, seg, S);
-        if (st == GE_OK) st = hub_exchange(s);
-        if (st != GE_OK) return st;
+    bool live = false; int32_t S = 8;
+    hub_plan(s, segments, &live, &S);
+    if (!live) {
+        for (int32_t seg = 0; seg < S; ++seg) {
+            ge_status st = ge::glove_epoch_segment(s->h, iteration, seg, S, 0, nullptr);
+            if (st == GE_OK) st = hub_exchange(s);
+            if (st != GE_OK) return st;
+        }
+        return ge::glove_epoch_finish(s->h, cost_sum);
     }
-    return ge::glove_epoch_finish(s->h, cost_sum);
+    // Live: ONE launch of the whole epoch (32 workgroups fewer: their 128 wavefront slots are where the small kernels and RCCL's run), and
+    // while it runs this thread watches the epoch's ticket counter and puts the r-th of S - 1 live exchanges on the hub stream when r / S
+    // of the tickets are out.  Every rank does exactly S - 1 of them (they are collective) whatever its own pace; an exchange that finds
+    // its turn late -- the ranks wait for each other inside the all-reduce, never the epoch kernels -- just runs later.  The epoch ends
+    // with the exact exchange of all hub rows (scalars included), as every segment of the segmented form does.
+    ge_status st = ge::glove_epoch_segment(s->h, iteration, 0, 1, 32, s->ev_reset);
+    if (st != GE_OK) return st;
+    const unsigned long long *counter = nullptr; int64_t tickets = 0; hipEvent_t done = nullptr;
+    if ((st = ge::glove_epoch_progress(s->h, &counter, &tickets, &done)) != GE_OK) return st;
+    GE_HIP(hipEventSynchronize(s->ev_reset));                 // from here on the counter is this epoch's
+    const bool dbg = std::getenv("GE_SYNC_DEBUG") != nullptr;
+    const auto t_launch = std::chrono::steady_clock::now();
+    bool finished = false;
+    int32_t late = 0;                                         // exchanges whose turn had passed by a whole interval when they were issued
+    for (int32_t r = 1; r < S; ++r) {
+        const unsigned long long target = (unsigned long long)(tickets * (int64_t)r / S), next = (unsigned long long)(tickets * (int64_t)(r + 1) / S);
+        while (!finished) {
+            GE_HIP(hipMemcpyAsync(s->progress, counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, s->hub_side));
+            GE_HIP(hipStreamSynchronize(s->hub_side));
+            if (*s->progress >= target) break;
+            const hipError_t q = hipEventQuery(done);         // (a kernel that ended early for any reason must not leave this loop spinning)
+            if (q == hipSuccess) { finished = true; break; }
+            if (q != hipErrorNotReady) return ge::fail(GE_ERR_HIP, "ge_sync_epoch: %s", hipGetErrorString(q));
+            std::this_thread::sleep_for(std::chrono::microseconds(60));
+        }
+        if (finished || *s->progress >= next) ++late;
+        const auto t_issue = std::chrono::steady_clock::now();
+        if ((st = live_exchange(s)) != GE_OK) return st;
+        if (dbg) {
+            (void)hipStreamSynchronize(s->hub_side);
+            std::fprintf(stderr, "[ge_sync_epoch live] rank %d exchange %d of %d: issued %.2f ms after the launch at ticket %llu of %lld (turn at %llu)%s, took %.2f ms\n", s->cfg.rank, r, S - 1,
+                         std::chrono::duration<double, std::milli>(t_issue - t_launch).count(), (unsigned long long)*s->progress, (long long)tickets, target, finished ? ", kernel finished" : "",
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_issue).count());
+        }
+    }
+    GE_HIP(hipStreamSynchronize(s->hub_side));                // the last land is in the tables before the exact exchange reads them
+    if ((st = hub_exchange(s)) != GE_OK) return st;           // (on the handle's stream: behind the epoch kernel)
+    if ((st = ge::glove_epoch_finish(s->h, cost_sum)) != GE_OK) return st;
+    // The live form never holds the epoch kernel back, so exchanges that cannot keep the pace (a slow transport, an epoch of a few
+    // milliseconds) would quietly reconcile the hub rows less often than planned -- which is what makes a sharded run unstable.  The
+    // ranks therefore vote after every live epoch: a quarter of the exchanges late on any rank in two epochs running, and the run continues
+    // in segments (the epoch then waits for every exchange).  One word, summed, on the exact exchange's path.
+    const float mine_late = (late * 4 > S) ? 1.0f : 0.0f;
+    GE_HIP(hipMemcpyAsync(s->hub_buf, &mine_late, sizeof(float), hipMemcpyHostToDevice, s->main));
+    GE_HIP(hipStreamSynchronize(s->main));
+    if ((st = allreduce_f32_small(s, s->hub_buf, 1)) != GE_OK) return st;
+    float any_late = 0.0f;
+    GE_HIP(hipMemcpyAsync(&any_late, s->hub_buf, sizeof(float), hipMemcpyDeviceToHost, s->main));
+    GE_HIP(hipStreamSynchronize(s->main));
+    s->live_epochs += 1; s->live_late += late;
+    s->late_streak = any_late > 0.0f ? s->late_streak + 1 : 0;
+    if (s->late_streak >= 2) {                                // (one such epoch does no harm -- a run needs several epochs of too few exchanges to leave its track)
+        s->live = false;
+        if (s->cfg.rank == 0) std::fprintf(stderr, "geglove: the live exchange of the hub rows fell behind the epoch (%d of %d late on this rank); continuing with the epoch in segments\n", late, S - 1);
+    }
+    return GE_OK;
 }
 // the hub rows of this run (ascending) and one small exchange of them on demand: for hosts that cut their epochs themselves, and for the parity test
 static ge_status ge_sync_hub_rows_impl(ge_sync *s, int32_t *out, int32_t capacity, int32_t *count) {
@@ -798,6 +994,36 @@ static ge_status hub_exchange_guarded(ge_sync *s) {
     } catch (const std::exception &e) { return ge::fail(GE_ERR_STATE, "internal error: %s", e.what()); }
 }
 ge_status ge_sync_hub_exchange(ge_sync *s) { return with_abort(s, hub_exchange_guarded(s)); }
+static ge_status live_exchange_guarded(ge_sync *s) {
+    try {
+        if (!s) return ge::fail(GE_ERR_ARG, "null ge_sync handle");
+        if (s->cfg.world == 1) return GE_OK;
+        if (!s->live) return ge::fail(GE_ERR_STATE, "this run has no live hub rows (bf16 rows, a host transport, GE_SYNC_EPOCH=segments, or no column that is a hub on every rank)");
+        GE_HIP(hipSetDevice(s->device));
+        ge_status st = live_exchange(s);
+        if (st == GE_OK) GE_HIP(hipStreamSynchronize(s->hub_side));
+        return st;
+    } catch (const std::exception &e) { return ge::fail(GE_ERR_STATE, "internal error: %s", e.what()); }
+}
+ge_status ge_sync_hub_exchange_live(ge_sync *s) { return with_abort(s, live_exchange_guarded(s)); }
+ge_status ge_sync_live_rows(ge_sync *s, int32_t *out, int32_t capacity, int32_t *count) {
+    if (!s || !count) return ge::fail(GE_ERR_ARG, "null argument");
+    *count = s->live ? s->n_live : 0;
+    if (out && capacity > 0 && *count > 0) {
+        if (hipSetDevice(s->device) != hipSuccess || hipMemcpy(out, s->live_list, sizeof(int32_t) * (size_t)std::min(capacity, *count), hipMemcpyDeviceToHost) != hipSuccess)
+            return ge::fail(GE_ERR_HIP, "ge_sync_live_rows: copy failed");
+    }
+    return GE_OK;
+}
+ge_status ge_sync_hub_plan(ge_sync *s, int32_t segments, int32_t *live, int32_t *exchanges, int32_t *live_rows) {
+    if (!s) return ge::fail(GE_ERR_ARG, "null ge_sync handle");
+    bool lv = false; int32_t n = 0;
+    if (s->cfg.world > 1 && s->n_hub > 0) hub_plan(s, segments, &lv, &n);
+    if (live) *live = lv ? 1 : 0;
+    if (exchanges) *exchanges = n;
+    if (live_rows) *live_rows = lv ? s->n_live : 0;
+    return GE_OK;
+}
 
 static ge_status epoch_guarded(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum) { GE_GUARD(ge_sync_epoch_impl(s, iteration, segments, cost_sum)); }
 ge_status ge_sync_epoch(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum) { return with_abort(s, epoch_guarded(s, iteration, segments, cost_sum)); }

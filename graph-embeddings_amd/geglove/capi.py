@@ -33,7 +33,7 @@ SYMBOLS = (
     "ge_glove_epoch_order", "ge_glove_get_perm", "ge_glove_rng_state", "ge_glove_last_kernel_ms", "ge_glove_get_info", "ge_glove_destroy",
     "ge_bca_build", "ge_coo_get", "ge_coo_destroy", "ge_exchange_turn_bf16", "ge_glove_context_layout",
     "ge_local_group_create", "ge_local_group_destroy", "ge_local_group_abort", "ge_rccl_unique_id", "ge_rccl_selftest", "ge_sync_cfg_size", "ge_sync_create", "ge_sync_begin", "ge_sync_finish", "ge_sync_turn", "ge_sync_sync",
-    "ge_sync_epoch", "ge_sync_hub_rows", "ge_sync_hub_exchange", "ge_sync_replicate", "ge_sync_allreduce_f64", "ge_sync_destroy",
+    "ge_sync_epoch", "ge_sync_hub_rows", "ge_sync_hub_exchange", "ge_sync_hub_exchange_live", "ge_sync_live_rows", "ge_sync_hub_plan", "ge_sync_replicate", "ge_sync_allreduce_f64", "ge_sync_destroy",
     "ge_sim_cfg_default", "ge_sim_cfg_size", "ge_sim_pattern_supported", "ge_similarity_pairs", "ge_sim_pairs_get", "ge_sim_pairs_destroy", "ge_copy_bandwidth", "ge_last_error", "ge_version", "ge_glove_cfg_size", "ge_bca_cfg_size", "ge_device_count",
 )
 
@@ -176,6 +176,9 @@ def lib():
     L.ge_sync_epoch.argtypes = [vp, C.c_int32, C.c_int32, f64p]
     L.ge_sync_hub_rows.argtypes = [vp, i32p, C.c_int32, i32p]
     L.ge_sync_hub_exchange.argtypes = [vp]
+    L.ge_sync_hub_exchange_live.argtypes = [vp]
+    L.ge_sync_live_rows.argtypes = [vp, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]
+    L.ge_sync_hub_plan.argtypes = [vp, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.ge_sync_replicate.argtypes = [vp, C.c_int32]
     L.ge_sync_allreduce_f64.argtypes = [vp, f64p, C.c_int32, C.c_int32]
     L.ge_sync_destroy.argtypes = [vp]; L.ge_sync_destroy.restype = None

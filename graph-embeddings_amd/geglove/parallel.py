@@ -178,6 +178,22 @@ class ContextSync:
         return out
 
     def hub_exchange(self): capi.check(capi.lib().ge_sync_hub_exchange(self._h))
+    def hub_exchange_live(self): capi.check(capi.lib().ge_sync_hub_exchange_live(self._h))
+
+    def live_rows(self):
+        """The context rows exchanged beside the running epoch kernel: hubs of the kernel on every rank."""
+        n = C.c_int32(0)
+        capi.check(capi.lib().ge_sync_live_rows(self._h, None, 0, C.byref(n)))
+        out = np.empty(n.value, np.int32)
+        if n.value:
+            capi.check(capi.lib().ge_sync_live_rows(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), n.value, C.byref(n)))
+        return out
+
+    def hub_plan(self, segments=0):
+        """What epoch(., segments) does with the hub rows: {"live": bool, "exchanges": per epoch, "live_rows": rows exchanged beside the kernel}."""
+        live, n, rows = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        capi.check(capi.lib().ge_sync_hub_plan(self._h, int(segments), C.byref(live), C.byref(n), C.byref(rows)))
+        return {"live": bool(live.value), "exchanges": n.value, "live_rows": rows.value}
 
     def begin(self, everything=False): capi.check(capi.lib().ge_sync_begin(self._h, int(bool(everything))))
     def finish(self): capi.check(capi.lib().ge_sync_finish(self._h))

@@ -442,20 +442,35 @@ ge_status ge_sync_begin(ge_sync *s, int32_t everything);
 ge_status ge_sync_finish(ge_sync *s);
 ge_status ge_sync_turn(ge_sync *s);
 ge_status ge_sync_sync(ge_sync *s);
-/* One epoch of a sharded run, to be called INSTEAD of ge_glove_epoch by every rank (collective): the handle's epoch runs in
- * `segments` launches (<= 0: the number of ranks, at least 8; at most 64) and behind each one the HUB rows of the context side
- * -- the union of the ranks' busy columns (count on a rank >= max(256, N_rank / 20 480)), a few thousand rows -- are reconciled exactly in one small fp32 all-reduce (rows and both
- * accumulators summed, cBias averaged over the ranks that moved it).  Without it eight ranks that each push a busy row for a whole
- * epoch from the same start overshoot where one GPU settles (measured: DESIGN.md 7); inside a GPU the same rows are held together by
- * publishing deltas every few updates, across GPUs by this.  ge_sync_turn / ge_sync_sync follow as before (they find nothing left to
- * do for the hub rows).  *cost_sum as ge_glove_epoch.  fp32 and bf16 rows (a bf16 handle reads and writes a hub row where IT keeps
- * it: the fp32 master row of a column that is a hub on this rank, else the bf16 table entry, stochastically rounded).  A one-rank run
- * and a run without hub columns get one plain ge_glove_epoch. */
+/* One epoch of a sharded run, to be called INSTEAD of ge_glove_epoch by every rank (collective).  On the way the HUB rows of the
+ * context side -- the union of the ranks' busy columns (count on a rank >= max(256, N_rank / 20 480)), a few thousand rows -- are
+ * reconciled `segments` times in small fp32 all-reduces (<= 0: as often as the busiest column asks for -- one exchange per 32 768
+ * updates that all ranks together put on it, at least max(8, ranks) --; at most 128 live, 64 in segments).
+ * Without it eight ranks that each push a busy row for a whole epoch from the same start overshoot where one GPU settles, and with too few
+ * exchanges for a very busy column the run leaves the single-GPU trajectory (measured: DESIGN.md 7); inside a GPU the same rows are held
+ * together by publishing deltas every few updates, across GPUs by this.  Two forms:
+ *   live      (fp32 rows over RCCL or a local group): the epoch is ONE launch and the exchanges run BESIDE it on a stream of their own --
+ *             the epoch kernel moves its hub columns by atomic adds only (a sharded handle counts every column that is busy on the rank
+ *             among them), so the other ranks' deltas are added the same way (k_live_take / k_live_land) -- paced by the epoch's
+ *             ticket counter; the epoch kernel never waits.  Should the exchanges fall behind the epoch (a quarter of them a whole
+ *             interval late on any rank, two epochs running: a slow transport, epochs of a few milliseconds), the ranks agree to
+ *             continue in segments.
+ *   segments  (bf16 rows, a host transport, GE_SYNC_EPOCH=segments): the epoch runs in `segments` launches and behind each one the hub
+ *             rows are reconciled exactly (rows and both accumulators summed, cBias averaged over the ranks that moved it).
+ * Both end the epoch with that exact exchange of all hub rows.  ge_sync_turn / ge_sync_sync follow as before (they find nothing left to
+ * do for the hub rows).  *cost_sum as ge_glove_epoch.  A bf16 handle reads and writes a hub row where IT keeps it: the fp32 master row
+ * of a column that is a hub on this rank, else the bf16 table entry, stochastically rounded.  A one-rank run and a run without hub
+ * columns get one plain ge_glove_epoch. */
 ge_status ge_sync_epoch(ge_sync *s, int32_t iteration, int32_t segments, double *cost_sum);
 /* The hub rows of this run (*count of them, ascending; out may be NULL or shorter), and ONE small exchange of them now (collective; what
  * ge_sync_epoch does behind every segment) -- for a host that cuts its epochs itself. */
 ge_status ge_sync_hub_rows(ge_sync *s, int32_t *out, int32_t capacity, int32_t *count);
 ge_status ge_sync_hub_exchange(ge_sync *s);
+/* One LIVE exchange now (collective; GE_ERR_STATE when the run has no live rows), and what ge_sync_epoch(s, ., segments, .) will do:
+ * *live = 1 beside the running kernel / 0 in segments, *exchanges per epoch, *live_rows = rows exchanged live (0 in segments). */
+ge_status ge_sync_hub_exchange_live(ge_sync *s);
+ge_status ge_sync_live_rows(ge_sync *s, int32_t *out, int32_t capacity, int32_t *count);      /* the rows a live exchange covers (ascending; as ge_sync_hub_rows) */
+ge_status ge_sync_hub_plan(ge_sync *s, int32_t segments, int32_t *live, int32_t *exchanges, int32_t *live_rows);
 /* Ends a run: lands what is in flight, exchanges everything not sent yet, then every rank takes rank src's fp32 tables. */
 ge_status ge_sync_replicate(ge_sync *s, int32_t src);
 /* n host doubles summed (op 0) or maximised (op 1) over the ranks through RCCL: the epoch's cost (Optimizer.java:94-96 needs

@@ -42,3 +42,6 @@ def gpu():
     n = capi.lib().ge_device_count()
     assert n > 0, "no gfx950 device visible: %s" % capi.lib().ge_last_error().decode()
     return n
+
+# rank-thread tests: a rank that never reaches an exchange aborts its group after three minutes instead of holding the run
+os.environ.setdefault("GE_LOCAL_GROUP_TIMEOUT_S", "180")

@@ -190,6 +190,86 @@ def test_hub_exchange_equals_the_model_bit_for_bit(gpu, D, layout):
     assert _spawn(_model_rank_main, (D, layout, 7, True)) == [1.0, 1.0]
 
 
+@pytest.mark.parametrize("D,world", [(32, 2), (200, 3)])
+def test_live_hub_exchange_equals_its_model_bit_for_bit(gpu, D, world):
+    """ge_sync_hub_exchange_live (k_live_take / k_live_land: what ge_sync_epoch runs BESIDE the epoch kernel), here with nothing running
+    beside it, so that it is a deterministic function: per live row and per element of the row and its accumulator row
+    own = table - base, sum = own_0 + own_1 + ... (rank order, from 0.0f), table += sum - own, base += sum -- the other ranks' moves are
+    ADDED to whatever the table holds, nothing is stored over it; rows outside the live set, and every scalar, stay as they are.  Two
+    rounds with moves in between (the second one checks the base), then the exact exchange and replicate(): identical replicas."""
+    import threading
+    import geglove
+    from geglove import parallel, synth
+    from helpers import make_config
+    V, N = 2000, 150000
+    I, J, X, xmax = synth.synthetic_coo(V, N, seed=3)
+    grp = parallel.LocalGroup(world)
+    bar = threading.Barrier(world)
+    snap = [dict() for _ in range(world)]          # per rank: what it held before / after every round
+    err = [None] * world
+    live = [None] * world
+
+    def body(r):
+        opt = sync = None
+        try:
+            rows = parallel.shard_rows(V, world, r)
+            si, sj, sx = parallel.shard_nonzeros(I, J, X, rows)
+            cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, row_range=rows)
+            opt = geglove.Adagrad(geglove.CooMatrix(V, si, sj, sx, xmax), cfg, cfg.costFunction())
+            bar.wait(timeout=300)
+            sync = parallel.ContextSync(opt, world, r, wire="f32", accum_every=2, local_group=grp)
+            live[r] = sync.live_rows()
+            rng = np.random.default_rng(11 + r)
+            snap[r]["base"] = {k: opt.get_state(k).copy() for k in CTX}
+            for rnd in range(2):
+                for k in CTX:
+                    cur = opt.get_state(k)
+                    mv = (rng.standard_normal(cur.size) * 0.01 * (rng.random(cur.size) < 0.4)).astype(np.float32)
+                    opt.set_state(k, (cur + mv).astype(np.float32))
+                snap[r]["before%d" % rnd] = {k: opt.get_state(k).copy() for k in CTX}
+                bar.wait(timeout=300)
+                sync.hub_exchange_live()
+                snap[r]["after%d" % rnd] = {k: opt.get_state(k).copy() for k in CTX}
+            sync.hub_exchange(); sync.sync(); sync.replicate()
+            snap[r]["final"] = {k: opt.get_state(k).copy() for k in CTX}
+        except Exception as e:              # noqa: BLE001
+            err[r] = e; grp.abort(); bar.abort()
+        finally:
+            if sync is not None: sync.close()
+            if opt is not None: opt.close()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th: t.start()
+    for t in th: t.join(timeout=600)
+    assert all(e is None for e in err), err
+    grp.close()
+    rows_live = live[0]
+    assert len(rows_live) > 0 and all(np.array_equal(rows_live, l) for l in live)
+    mask = np.zeros(V, bool); mask[rows_live] = True
+    base = {k: snap[0]["base"][k].copy() for k in ("context", "gsq_context")}       # the same on every rank (same seed, nothing exchanged yet)
+    for rnd in range(2):
+        for k in ("context", "gsq_context"):
+            own = [(snap[r]["before%d" % rnd][k] - base[k]).astype(np.float32) for r in range(world)]
+            total = np.zeros_like(own[0])
+            for r in range(world):
+                total = (total + own[r]).astype(np.float32)
+            for r in range(world):
+                want = snap[r]["before%d" % rnd][k].copy().reshape(V, -1)
+                add = (total - own[r]).astype(np.float32).reshape(V, -1)
+                want[mask] = (want[mask] + add[mask]).astype(np.float32)
+                assert np.array_equal(snap[r]["after%d" % rnd][k].reshape(V, -1), want), (rnd, k, r)
+            nb = base[k].reshape(V, -1).copy()
+            nb[mask] = (nb[mask] + total.reshape(V, -1)[mask]).astype(np.float32)
+            base[k] = nb.reshape(-1)
+        for k in ("cbias", "gsq_cbias"):                                              # the scalars are not the live exchange's
+            for r in range(world):
+                assert np.array_equal(snap[r]["after%d" % rnd][k], snap[r]["before%d" % rnd][k])
+    for r in range(1, world):
+        for k in CTX:
+            assert np.array_equal(snap[0]["final"][k], snap[r]["final"][k]), (r, k)
+    assert all(np.all(np.isfinite(snap[0]["final"][k])) for k in CTX)
+
+
 def test_ge_sync_argument_errors(gpu):
     import ctypes as C
     import geglove
@@ -318,13 +398,14 @@ def _oracle8():
     return _ORACLE8["ref"]
 
 
-def _run_rank_threads(world, V, N, D, epochs, exchange, wire, dtype="f32", lazy_every=2, fail_rank=None, hub_segments=None):
+def _run_rank_threads(world, V, N, D, epochs, exchange, wire, dtype="f32", lazy_every=2, fail_rank=None, hub_segments=None, plans=None, workers=None, own_streams=False):
     """One thread per rank; every rank owns a ge_glove handle (its block of focus rows) on device 0 and a ge_sync of the group."""
     import threading
     import geglove
     from geglove import parallel, synth
     from helpers import make_config
     I, J, X, xmax = synth.synthetic_coo(V, N, seed=13)
+    if plans is not None: plans.append((I, J, X, xmax))
     grp = parallel.LocalGroup(world)
     bar = threading.Barrier(world)
     cost = np.zeros((epochs, world))
@@ -337,15 +418,20 @@ def _run_rank_threads(world, V, N, D, epochs, exchange, wire, dtype="f32", lazy_
             si, sj, sx = parallel.shard_nonzeros(I, J, X, rows)
             # (library-default workers in both forms: the slots a real run reserves for RCCL's kernels, workers = -256, would leave a
             # matrix this small four workers and -- the hub set being relative to the worker count -- no hub columns at all)
-            cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, row_range=rows, dtype=dtype)
-            opt = geglove.Adagrad(geglove.CooMatrix(V, si, sj, sx, xmax), cfg, cfg.costFunction())
+            cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42, row_range=rows, dtype=dtype, **({"workers": workers} if workers else {}))
+            # own_streams: every rank's handle on a stream of its own, as one rank per GPU has it (the ranks of this process otherwise all
+            # launch on the null stream, where their epochs run one after the other)
+            stream = torch.cuda.Stream(device=0) if own_streams else None
+            opt = geglove.Adagrad(geglove.CooMatrix(V, si, sj, sx, xmax), cfg, cfg.costFunction(), **({"stream": stream.cuda_stream} if stream is not None else {}))
             bar.wait(timeout=600)
             sync = parallel.ContextSync(opt, world, r, wire=wire, accum_every=lazy_every, local_group=grp)
+            if plans is not None and r == 0: plans.append(sync.hub_plan(hub_segments or 0))
             for it in range(epochs):
                 if fail_rank == r and it == 1:
                     raise RuntimeError("rank %d leaves" % r)
                 cost[it, r] = sync.epoch(it) if hub_segments is None else (sync.epoch(it, hub_segments) if hub_segments > 0 else opt.epoch(it))
                 sync.turn() if (exchange == "overlap" and it >= 2) else sync.sync()      # (the hosts' policy: two synchronous epochs first)
+            if plans is not None and r == 0: plans.append(sync.hub_plan(hub_segments or 0))
             sync.replicate()
             out[r] = {k: opt.get_state(k) for k in CTX}
         except Exception as e:              # noqa: BLE001 -- reported by the caller
@@ -365,12 +451,19 @@ def _run_rank_threads(world, V, N, D, epochs, exchange, wire, dtype="f32", lazy_
     return cost.sum(axis=1) / len(I), out, err, alive
 
 
-@pytest.mark.parametrize("exchange,dtype", [("sync", "f32"), ("overlap", "f32"), ("sync", "bf16")])
-def test_eight_ranks_share_one_gpu(gpu, exchange, dtype):
+@pytest.mark.parametrize("exchange,dtype,form", [("sync", "f32", "live"), ("overlap", "f32", "live"), ("sync", "f32", "segments"), ("overlap", "f32", "segments"), ("sync", "bf16", "segments")])
+def test_eight_ranks_share_one_gpu(gpu, exchange, dtype, form, monkeypatch):
     """C4's shape (dim 200, fp32 rows, bf16 wire, accumulators every 2nd exchange) with EIGHT contributors per element, through
-    ge_sync_epoch (hub rows reconciled between the segments of the epoch) + the large exchange; and the same with bf16 rows (C5)."""
-    costs, out, err, alive = _run_rank_threads(W8["world"], W8["V"], W8["N"], W8["D"], W8["epochs"], exchange, "bf16", dtype=dtype)
+    ge_sync_epoch + the large exchange, in both forms of ge_sync_epoch: the hub rows exchanged LIVE beside the one launch of the epoch
+    (what fp32 rows get over RCCL and in a local group) and between the SEGMENTS of the epoch; and the same with bf16 rows (C5: segments)."""
+    if form == "segments" and dtype == "f32":
+        monkeypatch.setenv("GE_SYNC_EPOCH", "segments")
+    plans = []
+    costs, out, err, alive = _run_rank_threads(W8["world"], W8["V"], W8["N"], W8["D"], W8["epochs"], exchange, "bf16", dtype=dtype, plans=plans)
     assert not any(alive) and all(e is None for e in err), err
+    assert len(plans) == 3 and plans[1]["live"] == (form == "live") and plans[1]["exchanges"] >= 8, plans[1:]
+    if form == "live":
+        assert plans[1]["live_rows"] > 0           # (eight ranks' epochs of a few ms on one GPU: the live form may hand over to segments, plans[2])
     for r in range(1, W8["world"]):
         for k in CTX:
             if dtype == "bf16" and k == "context":            # bf16 rows live partly in per-rank fp32 master rows: equal up to one bf16 rounding
@@ -379,12 +472,58 @@ def test_eight_ranks_share_one_gpu(gpu, exchange, dtype):
             assert np.array_equal(out[0][k], out[r][k]), "rank %d's %s differs from rank 0's after replicate()" % (r, k)
     ref = _oracle8()
     ratio = np.array(costs) / np.array(ref)
-    print("eight ranks %s %s D=%d: cost / oracle %s" % (exchange, dtype, W8["D"], np.round(ratio, 3).tolist()))
+    print("eight ranks %s %s %s %s -> %s D=%d: cost / oracle %s" % (exchange, dtype, form, plans[1], plans[2], W8["D"], np.round(ratio, 3).tolist()))
     assert np.all(np.isfinite(costs)) and costs[-1] < costs[2] < costs[0]
     # bands: the blocked order and eight shards shift the first two epochs; from the third the sharded run tracks the
     # single-process oracle (synchronous: every rank sees the others' moves after each step; overlapped: one step late)
     np.testing.assert_allclose(costs[:2], ref[:2], rtol=0.25)
     np.testing.assert_allclose(costs[2:], ref[2:], rtol=0.06 if (exchange == "sync" and dtype == "f32") else 0.10)
+
+
+def _live_scenario():
+    """Body of test_two_ranks_live_exchange_beside_a_running_epoch, run in a process of its own (prints one JSON line)."""
+    import json
+    import geglove
+    from helpers import make_config
+    V, N, D, E = 100_000, 30_000_000, 200, 5        # (epochs of ~ 10 ms per rank: an exchange through the host takes ~ 1 ms)
+    plans = []
+    # (a stream per rank, and 2 000 workers per rank: on a GPU of its own a rank's epoch leaves 128 wavefront slots to the small kernels; two
+    # ranks that share one GPU must not fill it between them, or the small kernels queue behind the other rank's workgroups)
+    costs, out, err, alive = _run_rank_threads(2, V, N, D, E, "sync", "bf16", plans=plans, hub_segments=4, workers=2000, own_streams=True)
+    (I, J, X, xmax), before, after = plans
+    same = bool(all(np.array_equal(out[0][k], out[1][k]) for k in CTX)) if out[0] is not None and out[1] is not None else False
+    cfg = make_config(D, "glove", mode="hogwild", shuffle="device", seed=42)
+    one = geglove.Adagrad(geglove.CooMatrix(V, I, J, X, xmax), cfg, cfg.costFunction())
+    ref = [one.epoch(it) / len(I) for it in range(E)]
+    one.close()
+    print("LIVE " + json.dumps({"alive": [bool(a) for a in alive], "err": [None if e is None else str(e) for e in err], "before": before, "after": after,
+                                "replicas_identical": same, "costs": [float(c) for c in costs], "single_handle": [float(c) for c in ref]}), flush=True)
+
+
+def test_two_ranks_live_exchange_beside_a_running_epoch(gpu):
+    """The live form for real: two rank threads with 15 M nonzeros each (epochs of several milliseconds), four exchanges of the hub rows per
+    epoch BESIDE the epoch kernel -- take, host sum, atomic land on a stream of their own while the kernel's workers publish their own
+    deltas into the same rows.  The run must stay live (its exchanges keep the epoch's pace), end in identical replicas and follow a
+    single-handle run of the same library on the whole matrix (same seed; the sharded run's order differs, so: a band).  In a process of
+    its own: whether an exchange is late is a matter of host timing, and a test process that has run hundreds of GPU tests is no measure."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", "import conftest, test_parallel_gpu as T; T._live_scenario()"], cwd=here, capture_output=True, text=True, timeout=360,
+                       env=dict(os.environ, GE_SYNC_DEBUG="1", GE_LOCAL_GROUP_TIMEOUT_S="120"))
+    line = [l for l in r.stdout.splitlines() if l.startswith("LIVE ")]
+    assert r.returncode == 0 and line, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads(line[-1][5:])
+    assert not any(d["alive"]) and all(e is None for e in d["err"]), d
+    assert d["before"]["live"] and d["before"]["exchanges"] == 4 and d["before"]["live_rows"] > 0, d["before"]
+    assert d["after"]["live"], "the live exchange fell behind the epoch and handed over to segments:\n" + r.stderr[-6000:]
+    assert d["replicas_identical"]
+    costs, ref = np.array(d["costs"]), np.array(d["single_handle"])
+    print("two ranks live: cost / single handle %s (%d live rows)" % (np.round(costs / ref, 3).tolist(), d["before"]["live_rows"]))
+    assert np.all(np.isfinite(costs)) and costs[-1] < costs[1] < costs[0]
+    np.testing.assert_allclose(costs[2:], ref[2:], rtol=0.06)
+    np.testing.assert_allclose(costs[:2], ref[:2], rtol=0.15)
 
 
 def test_eight_ranks_need_the_hub_rows_reconciled_inside_the_epoch(gpu):
