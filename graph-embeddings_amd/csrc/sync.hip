@@ -407,6 +407,7 @@ struct ge_sync {
     hipEvent_t ev_reset = nullptr;                         // the epoch's ticket counter holds its first ticket
     unsigned long long *progress = nullptr;                // pinned host word the ticket counter is copied into
     bool live = false;                                     // ge_sync_epoch exchanges the live rows beside the epoch kernel (else: the epoch in segments)
+    int32_t live_cap = 128;                                // most live exchanges per epoch (halved once before the run gives the live form up)
     int32_t late_streak = 0;                               // consecutive live epochs in which some rank's exchanges fell behind
     int64_t live_epochs = 0, live_late = 0;                // epochs run live, and exchanges in them that were issued a whole interval late
     ge_context_layout lay{};
@@ -626,7 +627,7 @@ ge_status live_exchange(ge_sync *s) {
 // times per epoch, a segment costs a kernel boundary (0.18 ms at the bench size) plus the exchange and is capped at 64.
 void hub_plan(const ge_sync *s, int32_t segments, bool *live, int32_t *exchanges) {
     const bool lv = s->live && s->n_live > 0;
-    const int32_t cap = lv ? 128 : 64;
+    const int32_t cap = lv ? s->live_cap : 64;
     int32_t n = segments;
     if (n <= 0) {
         n = (int32_t)std::min<double>(cap, std::ceil((double)s->hub_top_count / 32768.0));
@@ -969,8 +970,14 @@ static ge_status ge_sync_epoch_impl(ge_sync *s, int32_t iteration, int32_t segme
     s->live_epochs += 1; s->live_late += late;
     s->late_streak = any_late > 0.0f ? s->late_streak + 1 : 0;
     if (s->late_streak >= 2) {                                // (one such epoch does no harm -- a run needs several epochs of too few exchanges to leave its track)
-        s->live = false;
-        if (s->cfg.rank == 0) std::fprintf(stderr, "geglove: the live exchange of the hub rows fell behind the epoch (%d of %d late on this rank); continuing with the epoch in segments\n", late, S - 1);
+        s->late_streak = 0;
+        if (s->live_cap > 64 && S > 64) {                     // first: no more live exchanges per epoch than the segmented form would make
+            s->live_cap = 64;
+            if (s->cfg.rank == 0) std::fprintf(stderr, "geglove: the live exchange of the hub rows fell behind the epoch (%d of %d late on this rank); at most 64 per epoch from here on\n", late, S - 1);
+        } else {
+            s->live = false;
+            if (s->cfg.rank == 0) std::fprintf(stderr, "geglove: the live exchange of the hub rows fell behind the epoch (%d of %d late on this rank); continuing with the epoch in segments\n", late, S - 1);
+        }
     }
     return GE_OK;
 }
