@@ -258,8 +258,10 @@ __global__ void k_mark(const int32_t *list, const int32_t *value, int32_t n, flo
 // next take finds exactly the rank's moves since this take: (row + others + later) - (base + sum) = later.  Nothing here waits for the
 // epoch kernel and nothing the epoch kernel does is lost; the scalars of the rows (bias, its accumulator: last-writer-wins stores in the
 // kernel) are left to the exact exchange at the end of the epoch.
+// (bf16 handles: `masters` / `mindex` = the fp32 master rows of the hub columns, where the epoch kernel keeps and moves such a row;
+// every row of the list has one on every rank)
 __global__ __launch_bounds__(256) void k_live_take(const int32_t *__restrict__ list, int32_t H, int32_t D,
-                                                   const float *rows, int64_t rows_stride, const float *__restrict__ rows_base,
+                                                   const float *rows, int64_t rows_stride, const float *masters, const int32_t *__restrict__ mindex, const float *__restrict__ rows_base,
                                                    const float *acc, int64_t acc_stride, const float *__restrict__ acc_base,
                                                    float *__restrict__ buf, float *__restrict__ own) {
     const int lane = threadIdx.x & 63;
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(256) void k_live_take(const int32_t *__restrict__ l
     if (h >= H) return;
     const int64_t v = list[h];
     for (int32_t d = lane; d < D; d += 64) {
-        const float r = __hip_atomic_load(rows + v * rows_stride + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float r = __hip_atomic_load(mindex ? masters + (int64_t)mindex[v] * D + d : rows + v * rows_stride + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float a = __hip_atomic_load(acc + v * acc_stride + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const float dr = r - rows_base[v * D + d], da = a - acc_base[v * D + d];
         const int64_t k = (int64_t)h * D + d;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void k_live_take(const int32_t *__restrict__ l
     }
 }
 __global__ __launch_bounds__(256) void k_live_land(const int32_t *__restrict__ list, int32_t H, int32_t D,
-                                                   float *rows, int64_t rows_stride, float *__restrict__ rows_base,
+                                                   float *rows, int64_t rows_stride, float *masters, const int32_t *__restrict__ mindex, float *__restrict__ rows_base,
                                                    float *acc, int64_t acc_stride, float *__restrict__ acc_base,
                                                    const float *__restrict__ buf, const float *__restrict__ own) {
     const int lane = threadIdx.x & 63;
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(256) void k_live_land(const int32_t *__restrict__ l
     const int64_t v = list[h];
     for (int32_t d = lane; d < D; d += 64) {
         const int64_t k = (int64_t)h * D + d, ka = (int64_t)H * D + k;
-        unsafeAtomicAdd(rows + v * rows_stride + d, buf[k] - own[k]);
+        unsafeAtomicAdd(mindex ? masters + (int64_t)mindex[v] * D + d : rows + v * rows_stride + d, buf[k] - own[k]);
         unsafeAtomicAdd(acc + v * acc_stride + d, buf[ka] - own[ka]);
         rows_base[v * D + d] += buf[k];
         acc_base[v * D + d] += buf[ka];
@@ -604,7 +606,9 @@ ge_status live_exchange(ge_sync *s) {
     const Entry &er = s->ent[0], &ea = s->ent[2];
     const int32_t H = s->n_live, D = s->lay.dim;
     const dim3 g((unsigned)((H + 3) / 4)), b(256);
-    hipLaunchKernelGGL(k_live_take, g, b, 0, s->hub_side, (const int32_t *)s->live_list, H, D, (const float *)er.table, er.t_stride, (const float *)er.base,
+    const bool r16 = er.bf16_rows;
+    hipLaunchKernelGGL(k_live_take, g, b, 0, s->hub_side, (const int32_t *)s->live_list, H, D, (const float *)er.table, er.t_stride,
+                       r16 ? (const float *)s->lay.hub_rows : (const float *)nullptr, r16 ? s->lay.hub_index : (const int32_t *)nullptr, (const float *)er.base,
                        (const float *)ea.table, ea.t_stride, (const float *)ea.base, s->live_buf, s->live_own);
     GE_HIP(hipGetLastError());
     const int64_t n = (int64_t)H * 2 * D;
@@ -613,7 +617,8 @@ ge_status live_exchange(ge_sync *s) {
         ge_status st = local_allreduce(s->loop, s->cfg.rank, s->live_buf, n, GE_DTYPE_F32, false, 0, s->hub_side);
         if (st != GE_OK) return st;
     } else GE_NCCL(rccl().AllReduce(s->live_buf, s->live_buf, (size_t)n, ncclFloat32, ncclSum, s->hub_comm, s->hub_side));
-    hipLaunchKernelGGL(k_live_land, g, b, 0, s->hub_side, (const int32_t *)s->live_list, H, D, er.table, er.t_stride, er.base, ea.table, ea.t_stride, ea.base,
+    hipLaunchKernelGGL(k_live_land, g, b, 0, s->hub_side, (const int32_t *)s->live_list, H, D, er.table, er.t_stride,
+                       r16 ? s->lay.hub_rows : (float *)nullptr, r16 ? s->lay.hub_index : (const int32_t *)nullptr, er.base, ea.table, ea.t_stride, ea.base,
                        (const float *)s->live_buf, (const float *)s->live_own);
     GE_HIP(hipGetLastError());
     return GE_OK;
@@ -863,7 +868,7 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
             const std::vector<int32_t> *kh = ge::glove_kernel_hubs(h);
             bool mine_ok = kh != nullptr;
             if (mine_ok && mine) for (int32_t v : *mine) if (!std::binary_search(kh->begin(), kh->end(), v)) { mine_ok = false; break; }
-            const bool can = s->lay.dtype != GE_DTYPE_BF16 && !s->tr.start && !(mode_env && std::strcmp(mode_env, "segments") == 0) && s->n_hub > 0;
+            const bool can = !s->tr.start && !(mode_env && std::strcmp(mode_env, "segments") == 0) && s->n_hub > 0;
             const float vote = (can && mine_ok) ? 0.0f : 1.0f;
             GE_TRYS(hipMemcpyAsync(flags, &vote, sizeof(float), hipMemcpyHostToDevice, s->main));
             GE_TRYS(hipStreamSynchronize(s->main));
@@ -872,8 +877,32 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
             float against = 1.0f;
             GE_TRYS(hipMemcpyAsync(&against, flags, sizeof(float), hipMemcpyDeviceToHost, s->main));
             GE_TRYS(hipStreamSynchronize(s->main));
-            if (against == 0.0f) {
-                s->live_list = s->hub_list; s->n_live = s->n_hub;
+            if (against == 0.0f && s->lay.dtype == GE_DTYPE_BF16) {
+                // bf16 rows: a hub row lives in an fp32 master row that the kernel moves by atomics -- where the column is a hub of the rank.
+                // The live set is therefore the columns that are hubs on EVERY rank; the few columns at the threshold that are not get
+                // the exact exchange at the end of the epoch only.
+                GE_TRYS(hipMemsetAsync(flags, 0, sizeof(float) * (size_t)V, s->main));
+                const int32_t nk = (int32_t)kh->size();
+                if (nk > 0) {
+                    int32_t *tk = nullptr;
+                    GE_TRYS(hipMalloc((void **)&tk, sizeof(int32_t) * (size_t)nk));
+                    s->owned.push_back(tk);
+                    GE_TRYS(hipMemcpyAsync(tk, kh->data(), sizeof(int32_t) * (size_t)nk, hipMemcpyHostToDevice, s->main));
+                    hipLaunchKernelGGL(k_mark, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, s->main, (const int32_t *)tk, (const int32_t *)nullptr, nk, flags);
+                }
+                st = allreduce_f32_small(s, flags, V);
+                if (st != GE_OK) { ge_sync_destroy(s); return st; }
+                GE_TRYS(hipMemcpyAsync(hf.data(), flags, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s->main));
+                GE_TRYS(hipStreamSynchronize(s->main));
+                std::vector<int32_t> lv;
+                for (int32_t v : all) if (hf[(size_t)v] == (float)cfg->world) lv.push_back(v);
+                s->n_live = (int32_t)lv.size();
+                if (s->n_live > 0) {
+                    GE_TRYS(s->alloc(&s->live_list, (size_t)s->n_live));
+                    GE_TRYS(hipMemcpy(s->live_list, lv.data(), sizeof(int32_t) * lv.size(), hipMemcpyHostToDevice));
+                }
+            } else if (against == 0.0f) { s->live_list = s->hub_list; s->n_live = s->n_hub; }
+            if (against == 0.0f && s->n_live > 0) {
                 GE_TRYS(s->alloc(&s->live_buf, (size_t)s->n_live * (size_t)(2 * D)));
                 GE_TRYS(s->alloc(&s->live_own, (size_t)s->n_live * (size_t)(2 * D)));
                 if (!s->hub_side) GE_TRYS(hipStreamCreateWithFlags(&s->hub_side, hipStreamNonBlocking));      // (a local group has no RCCL streams)

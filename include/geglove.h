@@ -449,13 +449,15 @@ ge_status ge_sync_sync(ge_sync *s);
  * Without it eight ranks that each push a busy row for a whole epoch from the same start overshoot where one GPU settles, and with too few
  * exchanges for a very busy column the run leaves the single-GPU trajectory (measured: DESIGN.md 7); inside a GPU the same rows are held
  * together by publishing deltas every few updates, across GPUs by this.  Two forms:
- *   live      (fp32 rows over RCCL or a local group): the epoch is ONE launch and the exchanges run BESIDE it on a stream of their own --
+ *   live      (over RCCL or a local group): the epoch is ONE launch and the exchanges run BESIDE it on a stream of their own --
  *             the epoch kernel moves its hub columns by atomic adds only (a sharded handle counts every column that is busy on the rank
  *             among them), so the other ranks' deltas are added the same way (k_live_take / k_live_land) -- paced by the epoch's
  *             ticket counter; the epoch kernel never waits.  Should the exchanges fall behind the epoch (a quarter of them a whole
  *             interval late on any rank, two epochs running: a slow transport, epochs of a few milliseconds), the ranks agree to
  *             continue in segments.
- *   segments  (bf16 rows, a host transport, GE_SYNC_EPOCH=segments): the epoch runs in `segments` launches and behind each one the hub
+ *             bf16 rows: on the fp32 master rows of the columns that are hubs on every rank (the few at the threshold that are not wait for
+ *             the end of the epoch).
+ *   segments  (a host transport, GE_SYNC_EPOCH=segments, a run that fell behind): the epoch runs in `segments` launches and behind each one the hub
  *             rows are reconciled exactly (rows and both accumulators summed, cBias averaged over the ranks that moved it).
  * Both end the epoch with that exact exchange of all hub rows.  ge_sync_turn / ge_sync_sync follow as before (they find nothing left to
  * do for the hub rows).  *cost_sum as ge_glove_epoch.  A bf16 handle reads and writes a hub row where IT keeps it: the fp32 master row
