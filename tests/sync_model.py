@@ -77,6 +77,28 @@ class SyncModel:
             c[idx] = new
             t[idx] = new
 
+    def hub_exchange_live(self, rows, n_rows, later=None):
+        """csrc/sync.hip k_live_take / k_live_land: the live exchange of the rows `rows` of the SUM tables that are not lazy-only scalars
+        (the context rows and their accumulator rows: what the epoch kernel moves by atomic adds).  own = table - c at the take; the
+        table may move on while the sum is under way (`later(e, idx)` returns what this rank adds meanwhile, or None); the land ADDS
+        sum - own to whatever the table holds then and sum to c."""
+        if self.world == 1 or len(rows) == 0:
+            return
+        idx = torch.as_tensor(rows, dtype=torch.long)
+        for e in self.ent:
+            t, c = e["t"].view(n_rows, -1), e["o"].view(n_rows, -1)
+            if e["mean"] or t.shape[1] == 1:                      # the rows' scalars wait for the exact exchange
+                continue
+            own = (t[idx] - c[idx]).contiguous()
+            total = own.clone()
+            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+            if later is not None:
+                mv = later(e, idx)
+                if mv is not None:
+                    t[idx] = t[idx] + mv
+            t[idx] = t[idx] + (total - own)
+            c[idx] = c[idx] + total
+
     def begin(self, everything=False): self._turn(False, True, everything)
     def finish(self): self._turn(True, False)
     def turn(self, everything=False): self._turn(True, True, everything)

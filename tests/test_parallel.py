@@ -345,3 +345,72 @@ def test_hub_rows_are_reconciled_exactly_and_left_alone_by_the_large_exchange():
         np.testing.assert_array_equal(f0, f1)                                    # after the large exchange (fp32 wire): replicas identical,
         np.testing.assert_array_equal(f0[hubs], a0[hubs])                        # the hub rows untouched by it
     assert got[0][2]["cbias"][17] == np.float32(start["cbias"][17] + got[0][1]["cbias"][17])      # the mean over ONE mover
+
+
+# ---- the LIVE exchange of the hub rows (ge_sync_epoch beside the running kernel), through the model --------------------------------
+
+def _live_rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    V, D = 40, 6
+    rng = np.random.default_rng(5)                       # the same start on every rank
+    st = {"context": torch.from_numpy(rng.standard_normal((V, D)).astype(np.float32)), "cbias": torch.from_numpy(rng.standard_normal(V).astype(np.float32)),
+          "gsq_context": torch.from_numpy(1 + rng.random((V, D)).astype(np.float32)), "gsq_cbias": torch.from_numpy(1 + rng.random(V).astype(np.float32))}
+    start = {k: v.clone() for k, v in st.items()}
+    sync = SyncModel(sums=[st["context"].view(-1)], means=[st["cbias"]], lazy_sums=[st["gsq_context"].view(-1), st["gsq_cbias"]], lazy_every=1, wire="f32")
+    hubs = np.array([3, 17, 18], np.int64)
+    mine = np.random.default_rng(100 + rank)
+    total_moves = {k: np.zeros(v.shape, np.float32) for k, v in st.items()}
+
+    def move(scale):
+        for k in st:
+            m = (mine.standard_normal(st[k].shape) * scale * (mine.random(st[k].shape) < 0.6)).astype(np.float32)
+            st[k].add_(torch.from_numpy(m)); total_moves[k] += m
+
+    def meanwhile(e, idx):                               # the table moves on while the sum is under way (the running epoch kernel)
+        m = (mine.standard_normal((len(idx), e["t"].view(V, -1).shape[1])) * 0.05).astype(np.float32)
+        name = "context" if e["t"].data_ptr() == st["context"].data_ptr() else "gsq_context"
+        total_moves[name].reshape(V, -1)[idx.numpy()] += m
+        return torch.from_numpy(m)
+
+    for rnd in range(3):                                 # three live exchanges inside an "epoch", moves before and during each
+        move(0.1)
+        sync.hub_exchange_live(hubs, V, later=meanwhile)
+    move(0.1)
+    sync.hub_exchange(hubs, V)                           # the exact exchange that ends the epoch
+    after_hub = {k: v.clone() for k, v in st.items()}
+    sync.sync()
+    q.put((rank, {k: v.numpy() for k, v in start.items()}, total_moves, {k: v.numpy() for k, v in after_hub.items()}, {k: v.numpy().copy() for k, v in st.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_live_exchange_loses_nothing_and_ends_in_the_consensus():
+    """The defining property of the live exchange (csrc/sync.hip, k_live_take / k_live_land), through the model on two gloo ranks: the
+    tables keep moving between the take and the land, the land only ADDS -- so after three live exchanges and the exact one that ends
+    the epoch, every hub row of the context table and of its accumulator table is start + EVERYTHING both ranks ever added to it (up to
+    fp32 rounding of the different summation order), identical on both ranks, and the large exchange leaves it alone."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_live_rank_main, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    got = {}
+    for _ in range(world):
+        r, start, moves, after_hub, final = q.get(timeout=300)
+        got[r] = (start, moves, after_hub, final)
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    hubs = [3, 17, 18]
+    start = got[0][0]
+    for k in ("context", "gsq_context"):
+        a0, a1 = got[0][2][k].reshape(40, -1), got[1][2][k].reshape(40, -1)
+        assert np.array_equal(a0[hubs], a1[hubs]), k                                   # identical replicas of the hub rows
+        want = start[k].reshape(40, -1)[hubs] + got[0][1][k].reshape(40, -1)[hubs] + got[1][1][k].reshape(40, -1)[hubs]
+        np.testing.assert_allclose(a0[hubs], want, rtol=0, atol=2e-6)                  # nothing lost, nothing counted twice
+        f0 = got[0][3][k].reshape(40, -1)
+        assert np.array_equal(f0[hubs], a0[hubs]), k                                   # the large exchange finds nothing to do for them
+    for k in CTX:                                                                       # and after it the whole tables agree
+        assert np.array_equal(got[0][3][k], got[1][3][k]), k
+
