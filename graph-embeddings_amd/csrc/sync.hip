@@ -183,6 +183,18 @@ __global__ __launch_bounds__(256) void k_sync_turn_flat4(float *__restrict__ tab
 // RANK, else the bf16 table entry; a landed value goes back the same way (the bf16 entry with stochastic rounding, whose error the large
 // exchange's take then finds in value - base and feeds back, as for every bf16 row).
 __device__ __forceinline__ uint32_t hub_mix32(uint32_t x) { x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13; x *= 0xC2B2AE3Du; x ^= x >> 16; return x; }
+// The merge of a hub row's summed deltas.  Between two exchanges every rank stepped with lr / sqrt(G0 + its OWN squared gradients), where
+// one sequential pass over the same updates would have had EVERYBODY's in the accumulator: summed as they are, W ranks' pushes overshoot by up
+// to sqrt(W), and a row that all ranks push hard -- a hub row early in training -- leaves the single-GPU trajectory (four ranks: bumps; six
+// ranks, eight exchanges per epoch: NaN in the third epoch).  The summed delta is therefore scaled, per element, by
+// sqrt((G0 + E / W) / (G0 + E)) -- G0 = the accumulator all ranks agreed on at the last exchange, E = the accumulator deltas of this one,
+// summed -- which is 1 while the accumulated G0 dominates and 1 / sqrt(W) when the exchange's own gradients do.  The accumulators
+// themselves add.  inv_world = 0: the plain sum (GE_SYNC_MERGE=sum).  IEEE operations only (the models in tests/ repeat them bit for bit).
+__device__ __forceinline__ float merge_scale(float g0, float e_sum, float inv_world) {
+    if (!(inv_world > 0.0f)) return 1.0f;
+    const float e = fmaxf(e_sum, 0.0f);
+    return __builtin_sqrtf((g0 + e * inv_world) / (g0 + e));
+}
 template <bool ROW16>
 __global__ __launch_bounds__(256) void k_hub_take(const int32_t *__restrict__ list, int32_t H, int32_t D,
                                                   const void *__restrict__ rows_, int64_t rows_stride, const float *__restrict__ rows_base,
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(256) void k_hub_land(const int32_t *__restrict__ li
                                                   float *__restrict__ acc, int64_t acc_stride, float *__restrict__ acc_base,
                                                   float *__restrict__ accb, int64_t accb_stride, float *__restrict__ accb_base,
                                                   float *__restrict__ bias, int64_t bias_stride, float *__restrict__ bias_base,
-                                                  const float *__restrict__ buf) {
+                                                  const float *__restrict__ buf, float inv_world) {
     const int lane = threadIdx.x & 63;
     const int32_t h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= H) return;
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(256) void k_hub_land(const int32_t *__restrict__ li
     const int32_t mi = ROW16 ? master_index[v] : -1;
     const float *const b_rows = buf, *const b_acc = buf + (int64_t)H * D, *const b_accb = b_acc + (int64_t)H * D, *const b_bias = b_accb + H, *const b_cnt = b_bias + H;
     for (int32_t d = lane; d < D; d += 64) {
-        const float c = rows_base[v * D + d] + b_rows[(int64_t)h * D + d];
+        const float c = rows_base[v * D + d] + merge_scale(acc_base[v * D + d], b_acc[(int64_t)h * D + d], inv_world) * b_rows[(int64_t)h * D + d];
         rows_base[v * D + d] = c;
         if (ROW16) {
             if (mi >= 0) masters[(int64_t)mi * D + d] = c;
@@ -280,16 +292,17 @@ __global__ __launch_bounds__(256) void k_live_take(const int32_t *__restrict__ l
 __global__ __launch_bounds__(256) void k_live_land(const int32_t *__restrict__ list, int32_t H, int32_t D,
                                                    float *rows, int64_t rows_stride, float *masters, const int32_t *__restrict__ mindex, float *__restrict__ rows_base,
                                                    float *acc, int64_t acc_stride, float *__restrict__ acc_base,
-                                                   const float *__restrict__ buf, const float *__restrict__ own) {
+                                                   const float *__restrict__ buf, const float *__restrict__ own, float inv_world) {
     const int lane = threadIdx.x & 63;
     const int32_t h = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= H) return;
     const int64_t v = list[h];
     for (int32_t d = lane; d < D; d += 64) {
         const int64_t k = (int64_t)h * D + d, ka = (int64_t)H * D + k;
-        unsafeAtomicAdd(mindex ? masters + (int64_t)mindex[v] * D + d : rows + v * rows_stride + d, buf[k] - own[k]);
+        const float merged = merge_scale(acc_base[v * D + d], buf[ka], inv_world) * buf[k];      // (the same on every rank: base and buf are)
+        unsafeAtomicAdd(mindex ? masters + (int64_t)mindex[v] * D + d : rows + v * rows_stride + d, merged - own[k]);
         unsafeAtomicAdd(acc + v * acc_stride + d, buf[ka] - own[ka]);
-        rows_base[v * D + d] += buf[k];
+        rows_base[v * D + d] += merged;
         acc_base[v * D + d] += buf[ka];
     }
 }
@@ -409,6 +422,7 @@ struct ge_sync {
     hipEvent_t ev_reset = nullptr;                         // the epoch's ticket counter holds its first ticket
     unsigned long long *progress = nullptr;                // pinned host word the ticket counter is copied into
     bool live = false;                                     // ge_sync_epoch exchanges the live rows beside the epoch kernel (else: the epoch in segments)
+    float merge_inv_world = 0.0f;                          // 1 / world: the hub rows' summed deltas are scaled by merge_scale(); 0: summed as they are
     int32_t live_cap = 128;                                // most live exchanges per epoch (halved once before the run gives the live form up)
     int32_t late_streak = 0;                               // consecutive live epochs in which some rank's exchanges fell behind
     int64_t live_epochs = 0, live_late = 0;                // epochs run live, and exchanges in them that were issued a whole interval late
@@ -593,9 +607,9 @@ ge_status hub_exchange(ge_sync *s) {
     s->seed = s->seed * 1664525u + 1013904223u;
     const uint32_t seed = s->seed ^ ((uint32_t)s->cfg.rank * 0x9E3779B1u);
     if (r16) hipLaunchKernelGGL(k_hub_land<true>, g, b, 0, s->main, s->hub_list, H, D, rows, rstride, er.base, s->lay.hub_rows, s->lay.hub_index, seed, ea.table, ea.t_stride, ea.base,
-                                eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf);
+                                eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf, s->merge_inv_world);
     else hipLaunchKernelGGL(k_hub_land<false>, g, b, 0, s->main, s->hub_list, H, D, rows, rstride, er.base, (float *)nullptr, (const int32_t *)nullptr, seed, ea.table, ea.t_stride, ea.base,
-                            eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf);
+                            eab.table, eab.t_stride, eab.base, eb.table, eb.t_stride, eb.base, s->hub_buf, s->merge_inv_world);
     GE_HIP(hipGetLastError());
     return GE_OK;
 }
@@ -619,7 +633,7 @@ ge_status live_exchange(ge_sync *s) {
     } else GE_NCCL(rccl().AllReduce(s->live_buf, s->live_buf, (size_t)n, ncclFloat32, ncclSum, s->hub_comm, s->hub_side));
     hipLaunchKernelGGL(k_live_land, g, b, 0, s->hub_side, (const int32_t *)s->live_list, H, D, er.table, er.t_stride,
                        r16 ? s->lay.hub_rows : (float *)nullptr, r16 ? s->lay.hub_index : (const int32_t *)nullptr, er.base, ea.table, ea.t_stride, ea.base,
-                       (const float *)s->live_buf, (const float *)s->live_own);
+                       (const float *)s->live_buf, (const float *)s->live_own, s->merge_inv_world);
     GE_HIP(hipGetLastError());
     return GE_OK;
 }
@@ -763,6 +777,8 @@ static ge_status ge_sync_create_impl(ge_glove *h, const ge_sync_cfg *cfg, ge_syn
     s->loop = cfg->local_group;
     if (s->loop && s->loop->world != cfg->world) { delete s; return ge::fail(GE_ERR_ARG, "local group has %d ranks, cfg.world is %d", s->loop->world, cfg->world); }
     if (s->cfg.accum_every == 0) s->cfg.accum_every = 4;
+    s->merge_inv_world = 1.0f / (float)std::max(1, cfg->world);
+    if (const char *e = std::getenv("GE_SYNC_MERGE")) if (std::strcmp(e, "sum") == 0) s->merge_inv_world = 0.0f;        // experiments: the hub rows' deltas summed as they are
     if (cfg->transport) s->tr = *cfg->transport;
     s->main = (hipStream_t)stream; s->device = device;
 #define GE_TRYS(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ge_status _s = ge::fail(_e == hipErrorOutOfMemory ? GE_ERR_OOM : GE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); ge_sync_destroy(s); return _s; } } while (0)

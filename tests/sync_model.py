@@ -10,8 +10,9 @@ import torch.distributed as dist
 
 
 class SyncModel:
-    def __init__(self, sums, means, lazy_sums=(), lazy_every=4, wire="bf16", group=None):
+    def __init__(self, sums, means, lazy_sums=(), lazy_every=4, wire="bf16", group=None, merge="adagrad"):
         self.group = group
+        self.merge = merge                   # how the hub rows' summed deltas are merged: "adagrad" (csrc/sync.hip merge_scale) or "sum"
         self.world = dist.get_world_size(group)
         self.wire = wire
         self.lazy_every = max(1, int(lazy_every))
@@ -19,6 +20,13 @@ class SyncModel:
         self.ent = ([dict(t=t, o=t.clone(), mean=False, lazy=False, work=None) for t in sums] +
                     [dict(t=t, o=t.clone(), mean=False, lazy=True, work=None) for t in lazy_sums] +
                     [dict(t=t, o=t.clone(), mean=True, lazy=False, work=None) for t in means])
+        # a row table's accumulator table: the lazy sum of the same size (context <-> gradSqContext)
+        for e in self.ent:
+            e["acc"] = None
+            if not e["mean"] and not e["lazy"]:
+                for a in self.ent:
+                    if a["lazy"] and a["t"].numel() == e["t"].numel():
+                        e["acc"] = a
         for e in self.ent:
             narrow = wire == "bf16" and not e["mean"]
             e["w"] = torch.empty(e["t"].shape, dtype=torch.bfloat16 if narrow else e["t"].dtype)
@@ -58,14 +66,25 @@ class SyncModel:
                 work.append(dist.all_reduce(w, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
                 e["work"] = work
 
+    def _merge_scale(self, g0, e_sum):
+        """csrc/sync.hip merge_scale: sqrt((G0 + E / W) / (G0 + E)) in fp32, operation for operation (1 for the plain sum)."""
+        if self.merge != "adagrad":
+            return torch.ones_like(g0)
+        inv_w = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(self.world), dtype=torch.float32)
+        e = torch.clamp(e_sum, min=0.0)
+        q = (g0 + e * inv_w) / (g0 + e)
+        return torch.sqrt(q.double()).float()             # (torch's fp32 sqrt on the CPU is a vector routine that is not correctly rounded; the fp64 one, rounded once more, is)
+
     def hub_exchange(self, rows, n_rows):
         """csrc/sync.hip k_hub_take / k_hub_land: the rows `rows` (of n_rows) of EVERY table reconciled now, in fp32 and exactly:
-        delta = table - c, summed over the ranks (means: divided by the number of ranks that moved the element), c += that, table = c."""
+        delta = table - c, summed over the ranks (means: divided by the number of ranks that moved the element; a row table: scaled
+        by merge_scale of its accumulator table's consensus and summed delta), c += that, table = c."""
         if self.world == 1 or len(rows) == 0:
             return
         idx = torch.as_tensor(rows, dtype=torch.long)
-        for e in self.ent:
-            t, c = e["t"].view(n_rows, -1), e["o"].view(n_rows, -1)
+        tot = {}
+        for e in self.ent:                                        # every table's summed delta first: the merge of a row table reads
+            t, c = e["t"].view(n_rows, -1), e["o"].view(n_rows, -1)   # its accumulator table's
             d = (t[idx] - c[idx]).contiguous()
             if e["mean"]:
                 cnt = d.ne(0).to(torch.float32)
@@ -73,6 +92,13 @@ class SyncModel:
             dist.all_reduce(d, op=dist.ReduceOp.SUM, group=self.group)
             if e["mean"]:
                 d = d / cnt.clamp(min=1.0)
+            tot[id(e)] = d
+        scale = {id(e): self._merge_scale(e["acc"]["o"].view(n_rows, -1)[idx], tot[id(e["acc"])]) for e in self.ent if e["acc"] is not None}
+        for e in self.ent:
+            t, c = e["t"].view(n_rows, -1), e["o"].view(n_rows, -1)
+            d = tot[id(e)]
+            if id(e) in scale:
+                d = scale[id(e)] * d
             new = c[idx] + d
             c[idx] = new
             t[idx] = new
@@ -81,23 +107,31 @@ class SyncModel:
         """csrc/sync.hip k_live_take / k_live_land: the live exchange of the rows `rows` of the SUM tables that are not lazy-only scalars
         (the context rows and their accumulator rows: what the epoch kernel moves by atomic adds).  own = table - c at the take; the
         table may move on while the sum is under way (`later(e, idx)` returns what this rank adds meanwhile, or None); the land ADDS
-        sum - own to whatever the table holds then and sum to c."""
+        merged - own to whatever the table holds then and merged to c (merged = the sum; a row table's: scaled by merge_scale)."""
         if self.world == 1 or len(rows) == 0:
             return
         idx = torch.as_tensor(rows, dtype=torch.long)
-        for e in self.ent:
+        live = [e for e in self.ent if not e["mean"] and e["t"].view(n_rows, -1).shape[1] > 1]      # the rows' scalars wait for the exact exchange
+        own, total = {}, {}
+        for e in live:                                            # take + all-reduce of both tables ...
             t, c = e["t"].view(n_rows, -1), e["o"].view(n_rows, -1)
-            if e["mean"] or t.shape[1] == 1:                      # the rows' scalars wait for the exact exchange
-                continue
-            own = (t[idx] - c[idx]).contiguous()
-            total = own.clone()
-            dist.all_reduce(total, op=dist.ReduceOp.SUM, group=self.group)
+            own[id(e)] = (t[idx] - c[idx]).contiguous()
+            total[id(e)] = own[id(e)].clone()
+            dist.all_reduce(total[id(e)], op=dist.ReduceOp.SUM, group=self.group)
+        scale = {id(e): self._merge_scale(e["acc"]["o"].view(n_rows, -1)[idx], total[id(e["acc"])]) for e in live if e["acc"] is not None}
+        for e in live:                                            # ... then the land (the row table's merge reads the accumulators' consensus BEFORE it moves)
+            t, c = e["t"].view(n_rows, -1), e["o"].view(n_rows, -1)
             if later is not None:
                 mv = later(e, idx)
                 if mv is not None:
                     t[idx] = t[idx] + mv
-            t[idx] = t[idx] + (total - own)
-            c[idx] = c[idx] + total
+            merged = scale[id(e)] * total[id(e)] if id(e) in scale else total[id(e)]
+            e["_land"] = (merged, own[id(e)])
+        for e in live:
+            t, c = e["t"].view(n_rows, -1), e["o"].view(n_rows, -1)
+            merged, o = e.pop("_land")
+            t[idx] = t[idx] + (merged - o)
+            c[idx] = c[idx] + merged
 
     def begin(self, everything=False): self._turn(False, True, everything)
     def finish(self): self._turn(True, False)

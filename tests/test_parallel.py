@@ -338,6 +338,11 @@ def test_hub_rows_are_reconciled_exactly_and_left_alone_by_the_large_exchange():
         tot = (d0 + d1).reshape(40, -1)
         if k == "cbias":
             tot = tot / np.maximum((d0 != 0).astype(np.float32) + (d1 != 0), 1).reshape(40, -1)
+        if k == "context":          # a row table: the summed delta scaled by sqrt((G0 + E / 2) / (G0 + E)) of its accumulator table (csrc/sync.hip merge_scale)
+            g0 = start["gsq_context"].reshape(40, -1)
+            e = np.maximum(((start["gsq_context"] + got[0][1]["gsq_context"]).astype(np.float32) - start["gsq_context"]) +
+                           ((start["gsq_context"] + got[1][1]["gsq_context"]).astype(np.float32) - start["gsq_context"]), np.float32(0)).reshape(40, -1)
+            tot = (np.sqrt((g0 + e * np.float32(0.5)) / (g0 + e)).astype(np.float32) * tot).astype(np.float32)
         np.testing.assert_array_equal(a0[hubs], (start[k].reshape(40, -1) + tot)[hubs])          # ... and are start + the merged moves
         rest = np.setdiff1d(np.arange(40), hubs)
         np.testing.assert_array_equal(a0[rest], (start[k] + got[0][1][k]).astype(np.float32).reshape(40, -1)[rest])   # nothing else moved
@@ -349,7 +354,7 @@ def test_hub_rows_are_reconciled_exactly_and_left_alone_by_the_large_exchange():
 
 # ---- the LIVE exchange of the hub rows (ge_sync_epoch beside the running kernel), through the model --------------------------------
 
-def _live_rank_main(rank, world, port, q):
+def _live_rank_main(rank, world, port, q, merge):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     V, D = 40, 6
@@ -357,7 +362,7 @@ def _live_rank_main(rank, world, port, q):
     st = {"context": torch.from_numpy(rng.standard_normal((V, D)).astype(np.float32)), "cbias": torch.from_numpy(rng.standard_normal(V).astype(np.float32)),
           "gsq_context": torch.from_numpy(1 + rng.random((V, D)).astype(np.float32)), "gsq_cbias": torch.from_numpy(1 + rng.random(V).astype(np.float32))}
     start = {k: v.clone() for k, v in st.items()}
-    sync = SyncModel(sums=[st["context"].view(-1)], means=[st["cbias"]], lazy_sums=[st["gsq_context"].view(-1), st["gsq_cbias"]], lazy_every=1, wire="f32")
+    sync = SyncModel(sums=[st["context"].view(-1)], means=[st["cbias"]], lazy_sums=[st["gsq_context"].view(-1), st["gsq_cbias"]], lazy_every=1, wire="f32", merge=merge)
     hubs = np.array([3, 17, 18], np.int64)
     mine = np.random.default_rng(100 + rank)
     total_moves = {k: np.zeros(v.shape, np.float32) for k, v in st.items()}
@@ -385,16 +390,18 @@ def _live_rank_main(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_live_exchange_loses_nothing_and_ends_in_the_consensus():
+@pytest.mark.parametrize("merge", ["sum", "adagrad"])
+def test_live_exchange_loses_nothing_and_ends_in_the_consensus(merge):
     """The defining property of the live exchange (csrc/sync.hip, k_live_take / k_live_land), through the model on two gloo ranks: the
     tables keep moving between the take and the land, the land only ADDS -- so after three live exchanges and the exact one that ends
-    the epoch, every hub row of the context table and of its accumulator table is start + EVERYTHING both ranks ever added to it (up to
-    fp32 rounding of the different summation order), identical on both ranks, and the large exchange leaves it alone."""
+    the epoch, every hub row of the accumulator table -- and, with the plain-sum merge, of the context table -- is start + EVERYTHING both
+    ranks ever added to it (up to fp32 rounding of the different summation order), identical on both ranks, and the large exchange leaves it
+    alone; with the library's merge (merge_scale: the row table's sums scaled by the accumulators) the replicas are identical all the same."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_live_rank_main, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_live_rank_main, args=(r, world, port, q, merge)) for r in range(world)]
     for p in procs: p.start()
     got = {}
     for _ in range(world):
@@ -408,7 +415,10 @@ def test_live_exchange_loses_nothing_and_ends_in_the_consensus():
         a0, a1 = got[0][2][k].reshape(40, -1), got[1][2][k].reshape(40, -1)
         assert np.array_equal(a0[hubs], a1[hubs]), k                                   # identical replicas of the hub rows
         want = start[k].reshape(40, -1)[hubs] + got[0][1][k].reshape(40, -1)[hubs] + got[1][1][k].reshape(40, -1)[hubs]
-        np.testing.assert_allclose(a0[hubs], want, rtol=0, atol=2e-6)                  # nothing lost, nothing counted twice
+        if merge == "sum" or k == "gsq_context":
+            np.testing.assert_allclose(a0[hubs], want, rtol=0, atol=2e-6)              # nothing lost, nothing counted twice
+        else:                                                                           # the row table's sums are scaled DOWN by at most 1 / sqrt(2): between the start and the plain sum ...
+            assert np.all(np.isfinite(a0[hubs])) and not np.allclose(a0[hubs], want, atol=1e-4)      # (... and not the plain sum)
         f0 = got[0][3][k].reshape(40, -1)
         assert np.array_equal(f0[hubs], a0[hubs]), k                                   # the large exchange finds nothing to do for them
     for k in CTX:                                                                       # and after it the whole tables agree

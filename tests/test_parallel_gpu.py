@@ -149,7 +149,12 @@ def _model_rank_main(rank, world, port, q, D, layout, steps, with_hubs=False):
                 sync.hub_exchange(); model.hub_exchange(hubs, V)
                 torch.cuda.synchronize()
                 for k in CTX:
-                    ok = ok and np.array_equal(opt.get_state(k), host[k].numpy())
+                    same = np.array_equal(opt.get_state(k), host[k].numpy())
+                    if not same and os.environ.get("GE_TEST_DEBUG"):
+                        a, b = opt.get_state(k).reshape(V, -1), host[k].numpy().reshape(V, -1)
+                        bad = np.nonzero((a != b).any(axis=1))[0]
+                        print("rank %d step %d hub exchange %d: %s differs in %d rows (hub rows among them: %d), max abs %.3g" % (rank, step, rep, k, len(bad), int(np.isin(bad, hubs).sum()), float(np.abs(a - b).max())), flush=True)
+                    ok = ok and same
                 keep = np.ones(V, bool); keep[hubs] = rep == 0            # first: everybody moves again; then: everybody but the hub rows
                 for k in CTX:
                     cur = opt.get_state(k)
@@ -194,7 +199,8 @@ def test_hub_exchange_equals_the_model_bit_for_bit(gpu, D, layout):
 def test_live_hub_exchange_equals_its_model_bit_for_bit(gpu, D, world, dtype):
     """ge_sync_hub_exchange_live (k_live_take / k_live_land: what ge_sync_epoch runs BESIDE the epoch kernel), here with nothing running
     beside it, so that it is a deterministic function: per live row and per element of the row and its accumulator row
-    own = table - base, sum = own_0 + own_1 + ... (rank order, from 0.0f), table += sum - own, base += sum -- the other ranks' moves are
+    own = table - base, sum = own_0 + own_1 + ... (rank order, from 0.0f), merged = sum (the row table: x merge_scale of the accumulators),
+    table += merged - own, base += merged -- the other ranks' moves are
     ADDED to whatever the table holds, nothing is stored over it; rows outside the live set, and every scalar, stay as they are (bf16
     handles: the live rows are fp32 master rows, the arithmetic is the same).  Two
     rounds with moves in between (the second one checks the base), then the exact exchange and replicate(): identical replicas."""
@@ -248,19 +254,27 @@ def test_live_hub_exchange_equals_its_model_bit_for_bit(gpu, D, world, dtype):
     assert len(rows_live) > 0 and all(np.array_equal(rows_live, l) for l in live)
     mask = np.zeros(V, bool); mask[rows_live] = True
     base = {k: snap[0]["base"][k].copy() for k in ("context", "gsq_context")}       # the same on every rank (same seed, nothing exchanged yet)
+    inv_w = np.float32(1.0) / np.float32(world)
     for rnd in range(2):
+        own, total = {}, {}
         for k in ("context", "gsq_context"):
-            own = [(snap[r]["before%d" % rnd][k] - base[k]).astype(np.float32) for r in range(world)]
-            total = np.zeros_like(own[0])
+            own[k] = [(snap[r]["before%d" % rnd][k] - base[k]).astype(np.float32) for r in range(world)]
+            total[k] = np.zeros_like(own[k][0])
             for r in range(world):
-                total = (total + own[r]).astype(np.float32)
+                total[k] = (total[k] + own[k][r]).astype(np.float32)
+        # the row table's sum is scaled by merge_scale of the accumulators' consensus BEFORE this exchange and their summed delta
+        e = np.maximum(total["gsq_context"], np.float32(0))
+        scale = np.sqrt(((base["gsq_context"] + e * inv_w).astype(np.float32) / (base["gsq_context"] + e).astype(np.float32)).astype(np.float32)).astype(np.float32)
+        merged = {"context": (scale * total["context"]).astype(np.float32), "gsq_context": total["gsq_context"]}
+        for k in ("context", "gsq_context"):
             for r in range(world):
                 want = snap[r]["before%d" % rnd][k].copy().reshape(V, -1)
-                add = (total - own[r]).astype(np.float32).reshape(V, -1)
+                add = (merged[k] - own[k][r]).astype(np.float32).reshape(V, -1)
                 want[mask] = (want[mask] + add[mask]).astype(np.float32)
                 assert np.array_equal(snap[r]["after%d" % rnd][k].reshape(V, -1), want), (rnd, k, r)
+        for k in ("context", "gsq_context"):
             nb = base[k].reshape(V, -1).copy()
-            nb[mask] = (nb[mask] + total.reshape(V, -1)[mask]).astype(np.float32)
+            nb[mask] = (nb[mask] + merged[k].reshape(V, -1)[mask]).astype(np.float32)
             base[k] = nb.reshape(-1)
         for k in ("cbias", "gsq_cbias"):                                              # the scalars are not the live exchange's
             for r in range(world):
@@ -482,7 +496,9 @@ def test_eight_ranks_share_one_gpu(gpu, exchange, dtype, form, monkeypatch):
     # bands: the blocked order and eight shards shift the first two epochs; from the third the sharded run tracks the
     # single-process oracle (synchronous: every rank sees the others' moves after each step; overlapped: one step late)
     np.testing.assert_allclose(costs[:2], ref[:2], rtol=0.25)
-    np.testing.assert_allclose(costs[2:], ref[2:], rtol=0.06 if (exchange == "sync" and dtype == "f32") else 0.10)
+    # (the first overlapped epoch reads 8 - 10 % BELOW the oracle: a rank reports the training cost of its own shard against a context side
+    # the synchronous epochs before it have just improved)
+    np.testing.assert_allclose(costs[2:], ref[2:], rtol=0.06 if (exchange == "sync" and dtype == "f32") else (0.10 if exchange == "sync" else 0.13))
 
 
 def _live_scenario():

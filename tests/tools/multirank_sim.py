@@ -39,7 +39,7 @@ def model_cost(I, J, X, xmax, focus, context, fb, cb, block=200_000):
     return tot / len(I)
 
 
-def run(V, N, D, W, epochs, delay, wire, seed=13, accum_every=1, hub_segments=0, hub_workers=180):
+def run(V, N, D, W, epochs, delay, wire, seed=13, accum_every=1, hub_segments=0, hub_workers=180, merge="adagrad"):
     I, J, X, xmax = synth.synthetic_coo(V, N, seed=seed)
     N = len(I)                                             # duplicates are merged by the generator
     single = O.Glove(V, D, I, J, X, xmax, O.COST_GLOVE, seed=42, threads=1)
@@ -78,6 +78,8 @@ def run(V, N, D, W, epochs, delay, wire, seed=13, accum_every=1, hub_segments=0,
                     si, sj, sx = shards[r]
                     p = perms[r][len(si) * sgm // hub_segments:len(si) * (sgm + 1) // hub_segments]
                     tot += float(O.adagrad_job(D, si[p], sj[p], sx[p], xmax, O.COST_GLOVE, st[r]))
+                g0 = base[0]["gsq_context"].reshape(V, -1)[hubs].copy()
+                e_sum = np.maximum(sum(st[r]["gsq_context"].reshape(V, -1)[hubs] - g0 for r in range(W)), 0.0)
                 for k in SUMS + MEANS:
                     cur = [st[r][k].reshape(V, -1)[hubs] for r in range(W)]
                     b0 = base[0][k].reshape(V, -1)[hubs]
@@ -85,6 +87,8 @@ def run(V, N, D, W, epochs, delay, wire, seed=13, accum_every=1, hub_segments=0,
                     tsum = sum(d)
                     if k in MEANS:
                         tsum = tsum / np.maximum(sum((x != 0).astype(np.float32) for x in d), 1.0)
+                    if k == "context" and merge == "adagrad":       # csrc/sync.hip merge_scale
+                        tsum = np.sqrt((g0 + e_sum / W) / (g0 + e_sum)).astype(np.float32) * tsum
                     new = b0 + tsum
                     for r in range(W):
                         st[r][k].reshape(V, -1)[hubs] = new
@@ -147,8 +151,9 @@ if __name__ == "__main__":
     ap.add_argument("--delays", default="0,1")
     ap.add_argument("--hub-segments", type=int, default=0, help="S > 0: ge_sync_epoch -- the hub rows are reconciled S times per epoch")
     ap.add_argument("--hub-workers", type=int, default=180, help="workers of the hub threshold 0.25 N_rank / workers")
+    ap.add_argument("--merge", default="adagrad", choices=["adagrad", "sum"], help="the hub rows' summed deltas: scaled by sqrt((G0 + E / W) / (G0 + E)) of the accumulators (the library) or summed as they are")
     a = ap.parse_args()
     for delay in [int(x) for x in a.delays.split(",")]:
-        ratio, ref = run(a.vocab, a.nnz, a.dim, a.ranks, a.epochs, delay, a.wire, accum_every=a.accum_every, hub_segments=a.hub_segments, hub_workers=a.hub_workers)
+        ratio, ref = run(a.vocab, a.nnz, a.dim, a.ranks, a.epochs, delay, a.wire, accum_every=a.accum_every, hub_segments=a.hub_segments, hub_workers=a.hub_workers, merge=a.merge)
         print("delay %d:" % delay, " ".join("%.3f" % x for x in ratio), flush=True)
     print("single-process cost:", " ".join("%.4f" % x for x in ref))
