@@ -458,7 +458,10 @@ ge_status ge_sync_sync(ge_sync *s);
  *             bf16 rows: on the fp32 master rows of the columns that are hubs on every rank (the few at the threshold that are not wait for
  *             the end of the epoch).
  *   segments  (a host transport, GE_SYNC_EPOCH=segments, a run that fell behind): the epoch runs in `segments` launches and behind each one the hub
- *             rows are reconciled exactly (rows and both accumulators summed, cBias averaged over the ranks that moved it).
+ *             rows are reconciled exactly (both accumulators summed, cBias averaged over the ranks that moved it, the parameter rows' summed
+ *             deltas scaled per element by sqrt((G0 + E / W) / (G0 + E)) -- G0 the accumulator at the last exchange, E this exchange's summed
+ *             accumulator deltas: every rank stepped without the others' gradients in its accumulator, and W such pushes summed as they
+ *             are overshoot by up to sqrt(W); GE_SYNC_MERGE=sum turns the scaling off --; the live form merges the same way).
  * Both end the epoch with that exact exchange of all hub rows.  ge_sync_turn / ge_sync_sync follow as before (they find nothing left to
  * do for the hub rows).  *cost_sum as ge_glove_epoch.  A bf16 handle reads and writes a hub row where IT keeps it: the fp32 master row
  * of a column that is a hub on this rank, else the bf16 table entry, stochastically rounded.  A one-rank run and a run without hub
