@@ -641,15 +641,17 @@ ge_status live_exchange(ge_sync *s) {
 // how ge_sync_epoch reconciles the hub rows: how often per epoch, and whether beside the running kernel (live) or between segments of it.
 // The busiest column decides.  Measured on the bench's matrix split over four ranks (625 k vertices, 103 M nonzeros, the busiest column
 // in every row: 625 k nonzeros): 8 exchanges per epoch -- 78 k updates of that row between two exchanges, all ranks together --
-// leave the single-GPU cost trajectory in epochs 3 to 5 and may not come back, 16 follow it within 2 %, 24 and more exactly.  So: one exchange
-// per 32 768 updates of the busiest column (20 there), at least max(8, ranks); a live exchange costs the epoch nothing and may come 128
-// times per epoch, a segment costs a kernel boundary (0.18 ms at the bench size) plus the exchange and is capped at 64.
+// leave the single-GPU cost trajectory in epochs 3 to 5 and may not come back, 16 follow it within 2 %, 24 and more exactly -- with the hub
+// rows' deltas summed as they are.  With merge_scale (above) 8 exchanges already stay within 2 - 4 % at four and at six ranks and 16 within
+// 1 %.  So: one exchange per 65 536 updates of the busiest column (10 there; 76 at the bench's eight-GPU size, where a rank puts four
+// times as many updates on that column per epoch), at least max(8, ranks); a live exchange costs the epoch nothing and may come 128 times
+// per epoch, a segment costs a kernel boundary (0.18 ms at the bench size) plus the exchange and is capped at 64.
 void hub_plan(const ge_sync *s, int32_t segments, bool *live, int32_t *exchanges) {
     const bool lv = s->live && s->n_live > 0;
     const int32_t cap = lv ? s->live_cap : 64;
     int32_t n = segments;
     if (n <= 0) {
-        n = (int32_t)std::min<double>(cap, std::ceil((double)s->hub_top_count / 32768.0));
+        n = (int32_t)std::min<double>(cap, std::ceil((double)s->hub_top_count / 65536.0));
         n = std::max(n, std::max(8, s->cfg.world));
     }
     *live = lv; *exchanges = std::min(n, cap);
