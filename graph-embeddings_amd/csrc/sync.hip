@@ -1005,7 +1005,7 @@ static ge_status ge_sync_epoch_impl(ge_sync *s, int32_t iteration, int32_t segme
     if ((st = ge::glove_epoch_finish(s->h, cost_sum)) != GE_OK) return st;
     // The live form never holds the epoch kernel back, so exchanges that cannot keep the pace (a slow transport, an epoch of a few
     // milliseconds) would quietly reconcile the hub rows less often than planned -- which is what makes a sharded run unstable.  The
-    // ranks therefore vote after every live epoch: a quarter of the exchanges late on any rank in two epochs running, and the run continues
+    // ranks therefore vote after every live epoch: a quarter of the exchanges late on half of the ranks in two epochs running, and the run continues
     // in segments (the epoch then waits for every exchange).  One word, summed, on the exact exchange's path.
     const float mine_late = (late * 4 > S) ? 1.0f : 0.0f;
     GE_HIP(hipMemcpyAsync(s->hub_buf, &mine_late, sizeof(float), hipMemcpyHostToDevice, s->main));
@@ -1015,7 +1015,9 @@ static ge_status ge_sync_epoch_impl(ge_sync *s, int32_t iteration, int32_t segme
     GE_HIP(hipMemcpyAsync(&any_late, s->hub_buf, sizeof(float), hipMemcpyDeviceToHost, s->main));
     GE_HIP(hipStreamSynchronize(s->main));
     s->live_epochs += 1; s->live_late += late;
-    s->late_streak = any_late > 0.0f ? s->late_streak + 1 : 0;
+    // (half of the ranks or more: a single rank whose shard is small ends its kernel early and issues its exchanges "late" without any harm --
+    // a transport that is too slow makes every rank late)
+    s->late_streak = any_late * 2.0f >= (float)s->cfg.world ? s->late_streak + 1 : 0;
     if (s->late_streak >= 2) {                                // (one such epoch does no harm -- a run needs several epochs of too few exchanges to leave its track)
         s->late_streak = 0;
         if (s->live_cap > 64 && S > 64) {                     // first: no more live exchanges per epoch than the segmented form would make

@@ -453,7 +453,7 @@ ge_status ge_sync_sync(ge_sync *s);
  *             the epoch kernel moves its hub columns by atomic adds only (a sharded handle counts every column that is busy on the rank
  *             among them), so the other ranks' deltas are added the same way (k_live_take / k_live_land) -- paced by the epoch's
  *             ticket counter; the epoch kernel never waits.  Should the exchanges fall behind the epoch (a quarter of them a whole
- *             interval late on any rank, two epochs running: a slow transport, epochs of a few milliseconds), the ranks agree to
+ *             interval late on half of the ranks, two epochs running: a slow transport, epochs of a few milliseconds), the ranks agree to
  *             continue in segments.
  *             bf16 rows: on the fp32 master rows of the columns that are hubs on every rank (the few at the threshold that are not wait for
  *             the end of the epoch).
