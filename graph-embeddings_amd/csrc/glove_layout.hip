@@ -167,6 +167,12 @@ ge_status build_blocked_layout(const LayoutRequest &rq, const int32_t *I, const 
         int64_t div = 20480, floor_n = 256;
         if (const char *e = std::getenv("GE_SYNC_HEAVY_DIV")) div = std::max<int64_t>(1, std::atoll(e));          // experiments (tools/r03/heavy_probe.sh)
         if (const char *e = std::getenv("GE_SYNC_HEAVY_MIN")) floor_n = std::max<int64_t>(1, std::atoll(e));
+        // more ranks, more contributors to a row that is summed once per epoch: from four ranks on the set grows with the number of ranks
+        // (this handle's share of the rows tells it: 1/8 of them -> twice the divisor).  Six ranks with the eight-rank threshold of the
+        // plain rule were 7 % behind the single GPU at epoch 12, with their own 3 % (profiles/r03_six_ranks_hub_threshold.json); the epoch
+        // kernel does not mind twice the hub columns on a shard (48.0 ms either way at the bench size).
+        const int64_t shards = rq.row_end > rq.row_begin ? std::max<int64_t>(1, (int64_t)V / (int64_t)(rq.row_end - rq.row_begin)) : 1;
+        if (shards > 4 && !std::getenv("GE_SYNC_HEAVY_DIV")) div = div * shards / 4;
         heavy_thr = std::max<int64_t>(floor_n, N / div);
     }
     if (N > 0 && rq.hot_columns != GE_HOT_NONE) {

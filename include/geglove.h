@@ -443,7 +443,7 @@ ge_status ge_sync_finish(ge_sync *s);
 ge_status ge_sync_turn(ge_sync *s);
 ge_status ge_sync_sync(ge_sync *s);
 /* One epoch of a sharded run, to be called INSTEAD of ge_glove_epoch by every rank (collective).  On the way the HUB rows of the
- * context side -- the union of the ranks' busy columns (count on a rank >= max(256, N_rank / 20 480)), a few thousand rows -- are
+ * context side -- the union of the ranks' busy columns (count on a rank >= max(256, N_rank / 20 480); from four ranks on the divisor grows with the ranks), a few thousand rows -- are
  * reconciled `segments` times in small fp32 all-reduces (<= 0: as often as the busiest column asks for -- one exchange per 65 536
  * updates that all ranks together put on it, at least max(8, ranks) --; at most 128 live, 64 in segments).
  * Without it eight ranks that each push a busy row for a whole epoch from the same start overshoot where one GPU settles, and with too few
